@@ -1,0 +1,273 @@
+"""ctypes binding of libpt_amd.so (the C ABI declared in include/pt_amd.h).
+
+This is plumbing for the Python-side drivers (bench.py, tests, multi-GPU launcher);
+all rendering happens in the HIP library.  There is NO CPU fallback: if the shared
+library is missing, or no HIP device is present when a render entry point is
+called, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpt_amd.so")
+PT_MAX_DEPTH = 64
+
+
+class PtGeom(C.Structure):
+    _fields_ = [("type", C.c_int32), ("materialid", C.c_int32), ("transform", C.c_float * 16),
+                ("inverseTransform", C.c_float * 16), ("invTranspose", C.c_float * 16)]
+
+
+class PtMaterial(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("specular_exponent", C.c_float), ("specular_color", C.c_float * 3),
+                ("hasReflective", C.c_float), ("hasRefractive", C.c_float), ("indexOfRefraction", C.c_float),
+                ("emittance", C.c_float)]
+
+
+class PtCamera(C.Structure):
+    _fields_ = [("resolution", C.c_int32 * 2), ("position", C.c_float * 3), ("lookAt", C.c_float * 3),
+                ("view", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3), ("fov", C.c_float * 2),
+                ("pixelLength", C.c_float * 2)]
+
+
+class PtBVHNode(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("left", C.c_int32), ("right", C.c_int32),
+                ("geomIndex", C.c_int32)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [("geoms", C.POINTER(PtGeom)), ("num_geoms", C.c_int32), ("materials", C.POINTER(PtMaterial)),
+                ("num_materials", C.c_int32), ("camera", PtCamera), ("trace_depth", C.c_int32)]
+
+
+class PtOptions(C.Structure):
+    _fields_ = [("device", C.c_int32), ("pixel_begin", C.c_int32), ("pixel_count", C.c_int32),
+                ("iters_per_batch", C.c_int32), ("num_queues", C.c_int32), ("blocks_per_cu", C.c_int32),
+                ("time_kernels", C.c_int32), ("reserved", C.c_int32 * 9)]
+
+
+class PtStats(C.Structure):
+    _fields_ = [("samples", C.c_int64), ("live_rays", C.c_int64 * PT_MAX_DEPTH), ("intersect_launches", C.c_int64),
+                ("intersect_ms", C.c_double), ("render_ms", C.c_double), ("num_cus", C.c_int32),
+                ("grid_blocks", C.c_int32), ("num_queues", C.c_int32), ("iters_per_batch", C.c_int32),
+                ("device_bytes", C.c_int64)]
+
+
+class PtError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+def lib() -> C.CDLL:
+    """Load libpt_amd.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_scene_load.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_scene_free.argtypes = [C.c_void_p]
+    L.pt_scene_free.restype = None
+    L.pt_scene_desc.argtypes = [C.c_void_p, C.POINTER(PtSceneDesc)]
+    L.pt_scene_iterations.argtypes = [C.c_void_p]
+    L.pt_scene_image_name.argtypes = [C.c_void_p]
+    L.pt_scene_image_name.restype = C.c_char_p
+    L.pt_build_bvh.argtypes = [C.POINTER(PtGeom), C.c_int, C.POINTER(PtBVHNode), C.c_int]
+    L.pt_build_transform.argtypes = [_fp, _fp, _fp, _fp]
+    L.pt_init.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions)]
+    L.pt_render.argtypes = [C.c_int, C.c_int]
+    L.pt_readback.argtypes = [_fp]
+    L.pt_readback_device.argtypes = [C.c_void_p]
+    L.pt_preview_rgba8.argtypes = [C.c_int, C.POINTER(C.c_uint8)]
+    L.pt_preview_rgba8_device.argtypes = [C.c_int, C.c_void_p]
+    L.pt_get_stats.argtypes = [C.POINTER(PtStats)]
+    L.pt_stage_generate.argtypes = [C.c_int, C.c_int, _fp, _fp]
+    L.pt_stage_intersect.argtypes = [C.c_int, _fp, _fp, _fp, _fp, _ip, _fp]
+    L.pt_stage_shade.argtypes = [C.c_int, C.c_int, _ip, _ip, _fp, _fp, _ip, _fp, _fp, _fp, _fp, _ip]
+    L.pt_save_png.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
+    L.pt_save_pfm.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise PtError(lib().pt_last_error().decode(errors="replace"))
+
+
+def _f(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_fp)
+
+
+def _i(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_ip)
+
+
+class Scene:
+    """Host scene: `new Scene(file)` + main.cpp's initial camera state (include/pt_amd.h: pt_scene_load)."""
+
+    def __init__(self, path: str, res: Optional[Tuple[int, int]] = None):
+        self._h = C.c_void_p()
+        w, h = res if res else (0, 0)
+        _check(lib().pt_scene_load(os.fsencode(path), int(w), int(h), C.byref(self._h)))
+        self.desc = PtSceneDesc()
+        _check(lib().pt_scene_desc(self._h, C.byref(self.desc)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and _lib is not None:
+            _lib.pt_scene_free(h)
+            self._h = C.c_void_p()
+
+    @property
+    def resolution(self) -> Tuple[int, int]:
+        return self.desc.camera.resolution[0], self.desc.camera.resolution[1]
+
+    @property
+    def trace_depth(self) -> int:
+        return self.desc.trace_depth
+
+    @trace_depth.setter
+    def trace_depth(self, d: int) -> None:
+        self.desc.trace_depth = int(d)
+
+    @property
+    def iterations(self) -> int:
+        return lib().pt_scene_iterations(self._h)
+
+    @property
+    def image_name(self) -> str:
+        return lib().pt_scene_image_name(self._h).decode()
+
+    def geoms(self):
+        return [self.desc.geoms[i] for i in range(self.desc.num_geoms)]
+
+    def materials(self):
+        return [self.desc.materials[i] for i in range(self.desc.num_materials)]
+
+    def bvh(self):
+        n = lib().pt_build_bvh(self.desc.geoms, self.desc.num_geoms, None, 0)
+        arr = (PtBVHNode * n)()
+        lib().pt_build_bvh(self.desc.geoms, self.desc.num_geoms, arr, n)
+        return arr
+
+
+def build_transform(trs: Sequence[float]):
+    t = np.asarray(trs, np.float32).copy()
+    m, i, it = (np.zeros(16, np.float32) for _ in range(3))
+    lib().pt_build_transform(_f(t), _f(m), _f(i), _f(it))
+    return m, i, it
+
+
+class Renderer:
+    """pathtraceInit / pathtrace / pathtraceFree over the C ABI (one global instance, like the reference)."""
+
+    def __init__(self, scene: Scene, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
+                 iters_per_batch: int = 0, num_queues: int = 0, blocks_per_cu: int = 0, time_kernels: bool = False):
+        opt = PtOptions()
+        opt.device = device
+        opt.pixel_begin = pixel_begin
+        opt.pixel_count = pixel_count
+        opt.iters_per_batch = iters_per_batch
+        opt.num_queues = num_queues
+        opt.blocks_per_cu = blocks_per_cu
+        opt.time_kernels = 1 if time_kernels else 0
+        self.scene = scene
+        w, h = scene.resolution
+        self.n = pixel_count if pixel_count > 0 else w * h - pixel_begin
+        self.pixel_begin = pixel_begin
+        _check(lib().pt_init(C.byref(scene.desc), C.byref(opt)))
+        self._live = True
+
+    def render(self, iter_first: int, iter_count: int) -> None:
+        _check(lib().pt_render(int(iter_first), int(iter_count)))
+
+    def sync(self) -> None:
+        _check(lib().pt_sync())
+
+    def readback(self) -> np.ndarray:
+        """Running SUM image of the tile, float32 [n, 3]."""
+        out = np.empty((self.n, 3), np.float32)
+        _check(lib().pt_readback(_f(out)))
+        return out
+
+    def readback_device(self, dev_ptr: int) -> None:
+        _check(lib().pt_readback_device(C.c_void_p(dev_ptr)))
+
+    def preview(self, iterations: int) -> np.ndarray:
+        out = np.empty((self.n, 4), np.uint8)
+        _check(lib().pt_preview_rgba8(int(iterations), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def stats(self) -> PtStats:
+        st = PtStats()
+        _check(lib().pt_get_stats(C.byref(st)))
+        return st
+
+    def reset_stats(self) -> None:
+        _check(lib().pt_reset_stats())
+
+    def free(self) -> None:
+        if self._live:
+            self._live = False
+            _check(lib().pt_free())
+
+    # ---- stage-level entry points (parity tests) ----
+    @staticmethod
+    def stage_generate(pix_begin: int, n: int):
+        o = np.zeros((3, n), np.float32)
+        d = np.zeros((3, n), np.float32)
+        _check(lib().pt_stage_generate(pix_begin, n, _f(o), _f(d)))
+        return o, d
+
+    @staticmethod
+    def stage_intersect(o: np.ndarray, d: np.ndarray):
+        n = o.shape[1]
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        t = np.zeros(n, np.float32)
+        nrm = np.zeros((3, n), np.float32)
+        mat = np.zeros(n, np.int32)
+        pt = np.zeros((3, n), np.float32)
+        _check(lib().pt_stage_intersect(n, _f(o), _f(d), _f(t), _f(nrm), _i(mat), _f(pt)))
+        return dict(t=t, nrm=nrm, mat=mat, pt=pt)
+
+    @staticmethod
+    def stage_shade(depth: int, it, pixel, hit: dict, o, d, color):
+        n = o.shape[1]
+        o, d, color = (np.ascontiguousarray(a, np.float32).copy() for a in (o, d, color))
+        alive = np.zeros(n, np.int32)
+        _check(lib().pt_stage_shade(n, depth, _i(np.ascontiguousarray(it, np.int32)),
+                                    _i(np.ascontiguousarray(pixel, np.int32)), _f(hit["t"]), _f(hit["nrm"]),
+                                    _i(hit["mat"]), _f(hit["pt"]), _f(o), _f(d), _f(color), _i(alive)))
+        return o, d, color, alive
+
+
+def pt_free() -> None:
+    _check(lib().pt_free())
+
+
+def save_png(path: str, rgb_sum: np.ndarray, w: int, h: int, samples: float) -> None:
+    a = np.ascontiguousarray(rgb_sum, np.float32)
+    if lib().pt_save_png(os.fsencode(path), _f(a), w, h, C.c_float(samples)) != 0:
+        raise PtError(f"cannot write {path}")
+
+
+def save_pfm(path: str, rgb_sum: np.ndarray, w: int, h: int, samples: float) -> None:
+    a = np.ascontiguousarray(rgb_sum, np.float32)
+    if lib().pt_save_pfm(os.fsencode(path), _f(a), w, h, C.c_float(samples)) != 0:
+        raise PtError(f"cannot write {path}")

@@ -1,0 +1,615 @@
+// pt_api.cpp — C ABI (include/pt_amd.h) and device-state owner of the MI355X
+// wavefront path tracer.  Host C++ calling the HIP runtime directly; replaces the
+// reference's pathtraceInit / pathtrace / pathtraceFree (src/pathtrace.cu:446-653).
+//
+// Differences from the reference's host loop by design:
+//   * no host<->device synchronisation inside an iteration (the reference does ~38),
+//     no per-iteration malloc/free, no per-iteration D2H frame copies or printf;
+//   * K iterations are traced as one wavefront batch so each launch has enough rays;
+//   * kernel sizes are fixed (persistent grid), live counts stay on the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "pt_device.h"
+#include "pt_kernels.h"
+#include "pt_scene.h"
+
+namespace {
+
+std::string g_err;
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return -1;
+}
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+struct Ctx {
+  bool live = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // scene
+  std::vector<PtGeom> geoms;
+  std::vector<PtMaterial> mats;
+  PtCamera cam{};
+  ptd::Camera dcam{};
+  int depth = 0;
+  // tile / batch geometry
+  int N = 0, pixel_begin = 0, K = 1;
+  int num_cus = 0, grid = 0;
+  ptd::Queues qs{};
+  int64_t stride = 0;  // plane stride = Q*cap
+  // device memory
+  std::vector<void*> allocs;
+  int64_t device_bytes = 0;
+  ptd::Node* d_nodes = nullptr;
+  ptd::Geom* d_geoms = nullptr;
+  ptd::Mat* d_mats = nullptr;
+  int num_nodes = 0;
+  ptd::PathBuf buf[2]{};
+  ptd::HitBuf hits{};
+  float* d_final = nullptr;
+  float* d_image = nullptr;
+  int32_t* d_cnt = nullptr;
+  unsigned long long* d_stats = nullptr;
+  // timing
+  bool time_kernels = false;
+  std::vector<EventPair> free_events, pending_isect, pending_render;
+  double isect_ms = 0, render_ms = 0;
+  int64_t isect_launches = 0;
+  int64_t samples = 0;
+};
+Ctx g;
+
+template <typename T>
+int dalloc(T** out, size_t count) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+  g.allocs.push_back(p);
+  g.device_bytes += (int64_t)bytes;
+  *out = reinterpret_cast<T*>(p);
+  return 0;
+}
+
+int get_events(EventPair* ev) {
+  if (!g.free_events.empty()) {
+    *ev = g.free_events.back();
+    g.free_events.pop_back();
+    return 0;
+  }
+  HIP_OK(hipEventCreate(&ev->a));
+  HIP_OK(hipEventCreate(&ev->b));
+  return 0;
+}
+int resolve_events() {  // requires the stream to be idle
+  for (auto& e : g.pending_isect) {
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e.a, e.b));
+    g.isect_ms += ms;
+    g.isect_launches++;
+    g.free_events.push_back(e);
+  }
+  g.pending_isect.clear();
+  for (auto& e : g.pending_render) {
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e.a, e.b));
+    g.render_ms += ms;
+    g.free_events.push_back(e);
+  }
+  g.pending_render.clear();
+  return 0;
+}
+
+// Re-emit the reference-order BVH (node, left, right links) in visiting order with
+// skip links (see ptd::Node).  Visiting order of the reference's stack walk is:
+// node, then its RIGHT subtree, then its LEFT subtree (pathtrace.cu:321-322).
+void thread_bvh(const std::vector<PtBVHNode>& in, int idx, std::vector<ptd::Node>& out) {
+  const PtBVHNode& n = in[idx];
+  const size_t self = out.size();
+  ptd::Node t{};
+  std::memcpy(t.bmin, n.bmin, 12);
+  std::memcpy(t.bmax, n.bmax, 12);
+  t.geom = n.left < 0 ? n.geomIndex : -1;
+  out.push_back(t);
+  if (n.left >= 0) {
+    thread_bvh(in, n.right, out);
+    thread_bvh(in, n.left, out);
+  }
+  out[self].skip = (int32_t)out.size();
+}
+
+void pack_rows(const float m16[16], float out12[12]) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 3; ++r) out12[c * 3 + r] = m16[c * 4 + r];
+}
+
+ptk::SceneTables tables() {
+  ptk::SceneTables t{};
+  t.nodes = g.d_nodes;
+  t.num_nodes = g.num_nodes;
+  t.geoms = g.d_geoms;
+  t.num_geoms = (int)g.geoms.size();
+  t.mats = g.d_mats;
+  t.num_mats = (int)g.mats.size();
+  return t;
+}
+
+int alloc_pathbuf(ptd::PathBuf* b, int64_t stride) {
+  b->stride = stride;
+  if (dalloc(&b->o, 3 * stride)) return -1;
+  if (dalloc(&b->d, 3 * stride)) return -1;
+  if (dalloc(&b->c, 3 * stride)) return -1;
+  if (dalloc(&b->slot, stride)) return -1;
+  return 0;
+}
+int alloc_hitbuf(ptd::HitBuf* h, int64_t stride) {
+  h->stride = stride;
+  if (dalloc(&h->t, stride)) return -1;
+  if (dalloc(&h->n, 3 * stride)) return -1;
+  if (dalloc(&h->mat, stride)) return -1;
+  if (dalloc(&h->p, 3 * stride)) return -1;
+  return 0;
+}
+
+int run_batch(int iter_first, int kb) {
+  ptk::BatchInfo b{};
+  b.iter_first = iter_first;
+  b.K = kb;
+  b.N = g.N;
+  b.pixel_begin = g.pixel_begin;
+  b.trace_depth = g.depth;
+  const size_t cnt_ints = (size_t)(g.depth + 1) * g.qs.Q * g.qs.cnt_stride;
+  HIP_OK(hipMemsetAsync(g.d_cnt, 0, cnt_ints * sizeof(int32_t), g.stream));
+  ptk::launch_generate(g.stream, g.grid, g.dcam, b, g.qs, g.buf[0], g.d_cnt);
+  const ptk::SceneTables sc = tables();
+  const size_t per_depth = (size_t)g.qs.Q * g.qs.cnt_stride;
+  for (int d = 0; d < g.depth; ++d) {
+    const int32_t* cin = g.d_cnt + per_depth * d;
+    int32_t* cout = g.d_cnt + per_depth * (d + 1);
+    EventPair ev{};
+    if (g.time_kernels) {
+      if (get_events(&ev)) return -1;
+      HIP_OK(hipEventRecord(ev.a, g.stream));
+    }
+    ptk::launch_intersect(g.stream, g.grid, sc, g.qs, cin, g.buf[d & 1], g.hits);
+    if (g.time_kernels) {
+      HIP_OK(hipEventRecord(ev.b, g.stream));
+      g.pending_isect.push_back(ev);
+    }
+    ptk::launch_shade(g.stream, g.grid, sc, b, d, g.qs, cin, cout, g.buf[d & 1], g.hits, g.buf[(d + 1) & 1], g.d_final);
+  }
+  ptk::launch_count_stats(g.stream, g.qs, g.d_cnt, g.depth, g.d_stats);
+  ptk::launch_gather(g.stream, b, g.d_final, g.d_image);
+  HIP_OK(hipGetLastError());
+  g.samples += (int64_t)kb * g.N;
+  if (g.pending_isect.size() > 16384) {
+    HIP_OK(hipStreamSynchronize(g.stream));
+    if (resolve_events()) return -1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+namespace {
+struct Scratch {  // frees on scope exit
+  std::vector<void*> p;
+  ~Scratch() {
+    for (void* q : p) (void)hipFree(q);
+  }
+  template <typename T>
+  T* get(size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(n * sizeof(T), 16)) != hipSuccess) return nullptr;
+    p.push_back(q);
+    return reinterpret_cast<T*>(q);
+  }
+};
+ptd::Queues single_queue(int n) {
+  ptd::Queues qs{};
+  qs.Q = 1;
+  qs.cap = ((n + 63) / 64) * 64;
+  qs.W = g.grid * ptk::kWavesPerBlock;
+  qs.cnt_stride = 16;
+  return qs;
+}
+}  // namespace
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+
+// ---- scene -----------------------------------------------------------------
+struct PtScene {
+  pt::Scene scene;
+  explicit PtScene(const std::string& f) : scene(f) {}
+};
+
+int pt_scene_load(const char* path, int res_w, int res_h, PtScene** out) {
+  if (!path || !out) return fail("pt_scene_load: null argument");
+  try {
+    PtScene* s = new PtScene(path);
+    if (res_w > 0 && res_h > 0) s->scene.overrideResolution(res_w, res_h);
+    s->scene.applyInitialCameraState();
+    *out = s;
+    return 0;
+  } catch (const std::exception& e) {
+    return fail("pt_scene_load: %s", e.what());
+  }
+}
+void pt_scene_free(PtScene* s) { delete s; }
+int pt_scene_desc(const PtScene* s, PtSceneDesc* out) {
+  if (!s || !out) return fail("pt_scene_desc: null argument");
+  *out = s->scene.desc();
+  return 0;
+}
+int pt_scene_iterations(const PtScene* s) { return s ? (int)s->scene.state.iterations : 0; }
+const char* pt_scene_image_name(const PtScene* s) { return s ? s->scene.state.imageName.c_str() : ""; }
+
+int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap) {
+  std::vector<PtBVHNode> nodes;
+  pt::buildBVH(geoms, num_geoms, nodes);
+  if (out) std::memcpy(out, nodes.data(), sizeof(PtBVHNode) * std::min<size_t>(nodes.size(), (size_t)std::max(cap, 0)));
+  return (int)nodes.size();
+}
+
+int pt_build_transform(const float* trs, float* transform, float* inverse, float* invTranspose) {
+  if (!trs || !transform || !inverse || !invTranspose) return fail("pt_build_transform: null argument");
+  pt::buildTransform(trs, transform, inverse, invTranspose);
+  return 0;
+}
+
+// ---- renderer ----------------------------------------------------------------
+int pt_free(void) {
+  if (!g.live && g.allocs.empty()) return 0;  // pathtraceFree() before init / twice is legal (main.cpp:134)
+  (void)hipSetDevice(g.device);
+  if (g.stream) (void)hipStreamSynchronize(g.stream);
+  for (void* p : g.allocs) (void)hipFree(p);
+  auto kill = [](std::vector<EventPair>& v) {
+    for (auto& e : v) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
+    v.clear();
+  };
+  kill(g.free_events);
+  kill(g.pending_isect);
+  kill(g.pending_render);
+  if (g.stream) (void)hipStreamDestroy(g.stream);
+  g = Ctx();
+  return 0;
+}
+
+int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
+  if (!sc) return fail("pt_init: null scene");
+  if (sc->num_geoms <= 0 || !sc->geoms) return fail("pt_init: scene has no geometry");
+  if (sc->num_materials <= 0 || !sc->materials) return fail("pt_init: scene has no materials");
+  if (sc->trace_depth <= 0 || sc->trace_depth > PT_MAX_DEPTH) return fail("pt_init: trace_depth %d out of range", sc->trace_depth);
+  const int W = sc->camera.resolution[0], H = sc->camera.resolution[1];
+  if (W <= 0 || H <= 0 || (int64_t)W * H > (1ll << 30)) return fail("pt_init: bad resolution %dx%d", W, H);
+  for (int i = 0; i < sc->num_geoms; ++i)
+    if (sc->geoms[i].materialid < 0 || sc->geoms[i].materialid >= sc->num_materials)
+      return fail("pt_init: geom %d references material %d of %d", i, sc->geoms[i].materialid, sc->num_materials);
+  PtOptions opt{};
+  if (opt_in) opt = *opt_in;
+  pt_free();
+
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail("pt_init: no HIP device (this library has no CPU fallback)");
+  if (opt.device < 0 || opt.device >= ndev) return fail("pt_init: device %d of %d", opt.device, ndev);
+  g.device = opt.device;
+  HIP_OK(hipSetDevice(g.device));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, g.device));
+  g.num_cus = prop.multiProcessorCount;
+  HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  g.live = true;
+
+  g.geoms.assign(sc->geoms, sc->geoms + sc->num_geoms);
+  g.mats.assign(sc->materials, sc->materials + sc->num_materials);
+  g.cam = sc->camera;
+  g.depth = sc->trace_depth;
+  g.dcam.res_x = W, g.dcam.res_y = H;
+  std::memcpy(g.dcam.pos, g.cam.position, 12);
+  std::memcpy(g.dcam.view, g.cam.view, 12);
+  std::memcpy(g.dcam.up, g.cam.up, 12);
+  std::memcpy(g.dcam.right, g.cam.right, 12);
+  g.dcam.pl_x = g.cam.pixelLength[0], g.dcam.pl_y = g.cam.pixelLength[1];
+
+  g.pixel_begin = opt.pixel_begin;
+  g.N = opt.pixel_count > 0 ? opt.pixel_count : W * H - opt.pixel_begin;
+  if (g.pixel_begin < 0 || g.N <= 0 || (int64_t)g.pixel_begin + g.N > (int64_t)W * H)
+    return fail("pt_init: tile [%d, +%d) outside %dx%d", opt.pixel_begin, opt.pixel_count, W, H);
+
+  // batch size: enough paths in flight to fill the chip a few times over; slots are int32
+  int K = opt.iters_per_batch;
+  if (K <= 0) {
+    const int64_t target = 4ll << 20;  // ~4 M paths per batch
+    K = (int)std::max<int64_t>(1, std::min<int64_t>(64, (target + g.N - 1) / g.N));
+  }
+  while ((int64_t)K * g.N > (1ll << 30) && K > 1) --K;
+  g.K = K;
+
+  const int bpc = opt.blocks_per_cu > 0 ? opt.blocks_per_cu : 8;
+  int Q = opt.num_queues > 0 ? opt.num_queues : 256;
+  const int grid = std::max(1, g.num_cus * bpc);
+  const int Wv = grid * ptk::kWavesPerBlock;
+  if (Q > Wv) Q = Wv;
+  while (Wv % Q) --Q;  // every queue is served by the same number of waves
+  g.grid = grid;
+  g.qs.Q = Q;
+  g.qs.W = Wv;
+  g.qs.cnt_stride = 16;
+  const int64_t total = (int64_t)K * g.N;
+  const int64_t chunks = (total + 63) / 64;
+  g.qs.cap = (int)(((chunks + Q - 1) / Q) * 64);
+  g.stride = (int64_t)Q * g.qs.cap;
+
+  // scene tables
+  std::vector<PtBVHNode> ref_nodes;
+  pt::buildBVH(g.geoms.data(), (int)g.geoms.size(), ref_nodes);
+  std::vector<ptd::Node> nodes;
+  nodes.reserve(ref_nodes.size());
+  thread_bvh(ref_nodes, 0, nodes);
+  g.num_nodes = (int)nodes.size();
+  std::vector<ptd::Geom> dg(g.geoms.size());
+  for (size_t i = 0; i < g.geoms.size(); ++i) {
+    std::memset(&dg[i], 0, sizeof(ptd::Geom));
+    pack_rows(g.geoms[i].inverseTransform, dg[i].inv);
+    pack_rows(g.geoms[i].transform, dg[i].xf);
+    pack_rows(g.geoms[i].invTranspose, dg[i].invT);
+    dg[i].type = g.geoms[i].type;
+    dg[i].material = g.geoms[i].materialid;
+  }
+  std::vector<ptd::Mat> dm(g.mats.size());
+  for (size_t i = 0; i < g.mats.size(); ++i) {
+    std::memset(&dm[i], 0, sizeof(ptd::Mat));
+    std::memcpy(dm[i].color, g.mats[i].color, 12);
+    std::memcpy(dm[i].spec, g.mats[i].specular_color, 12);
+    dm[i].reflective = g.mats[i].hasReflective;
+    dm[i].refractive = g.mats[i].hasRefractive;
+    dm[i].emittance = g.mats[i].emittance;
+  }
+  if (dm.size() * sizeof(ptd::Mat) > 60 * 1024) return fail("pt_init: %zu materials exceed the LDS table", dm.size());
+  if (dalloc(&g.d_nodes, nodes.size()) || dalloc(&g.d_geoms, dg.size()) || dalloc(&g.d_mats, dm.size())) return -1;
+  HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
+
+  // path state
+  if (alloc_pathbuf(&g.buf[0], g.stride) || alloc_pathbuf(&g.buf[1], g.stride) || alloc_hitbuf(&g.hits, g.stride)) return -1;
+  if (dalloc(&g.d_final, 3 * (size_t)total) || dalloc(&g.d_image, 3 * (size_t)g.N)) return -1;
+  if (dalloc(&g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;
+  if (dalloc(&g.d_stats, PT_MAX_DEPTH)) return -1;
+  HIP_OK(hipMemset(g.d_image, 0, 3 * (size_t)g.N * sizeof(float)));
+  HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));
+  g.time_kernels = opt.time_kernels != 0;
+  HIP_OK(hipDeviceSynchronize());
+  return 0;
+}
+
+int pt_render(int iter_first, int iter_count) {
+  if (!g.live) return fail("pt_render: pt_init has not been called");
+  if (iter_count <= 0) return 0;
+  HIP_OK(hipSetDevice(g.device));
+  EventPair ev{};
+  if (get_events(&ev)) return -1;
+  HIP_OK(hipEventRecord(ev.a, g.stream));
+  const int end = iter_first + iter_count;
+  for (int it = iter_first; it < end; it += g.K)
+    if (run_batch(it, std::min(g.K, end - it))) return -1;
+  HIP_OK(hipEventRecord(ev.b, g.stream));
+  g.pending_render.push_back(ev);
+  return 0;
+}
+
+int pt_sync(void) {
+  if (!g.live) return fail("pt_sync: pt_init has not been called");
+  HIP_OK(hipSetDevice(g.device));
+  HIP_OK(hipStreamSynchronize(g.stream));
+  return resolve_events();
+}
+
+int pt_readback(float* out) {
+  if (!g.live) return fail("pt_readback: pt_init has not been called");
+  if (!out) return fail("pt_readback: null buffer");
+  HIP_OK(hipSetDevice(g.device));
+  HIP_OK(hipMemcpyAsync(out, g.d_image, 3 * (size_t)g.N * sizeof(float), hipMemcpyDeviceToHost, g.stream));
+  return pt_sync();
+}
+
+int pt_readback_device(void* out) {
+  if (!g.live) return fail("pt_readback_device: pt_init has not been called");
+  if (!out) return fail("pt_readback_device: null buffer");
+  HIP_OK(hipSetDevice(g.device));
+  HIP_OK(hipMemcpyAsync(out, g.d_image, 3 * (size_t)g.N * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
+  return pt_sync();
+}
+
+int pt_preview_rgba8(int iterations, uint8_t* rgba_host) {
+  if (!g.live) return fail("pt_preview_rgba8: pt_init has not been called");
+  if (!rgba_host || iterations <= 0) return fail("pt_preview_rgba8: bad argument");
+  HIP_OK(hipSetDevice(g.device));
+  uchar4* d = nullptr;
+  HIP_OK(hipMalloc((void**)&d, (size_t)g.N * 4));
+  ptk::launch_preview(g.stream, g.N, iterations, g.d_image, d);
+  hipError_t e = hipMemcpyAsync(rgba_host, d, (size_t)g.N * 4, hipMemcpyDeviceToHost, g.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail("pt_preview_rgba8: %s", hipGetErrorString(e));
+  return 0;
+}
+
+
+int pt_preview_rgba8_device(int iterations, void* rgba_dev) {
+  if (!g.live) return fail("pt_preview_rgba8_device: pt_init has not been called");
+  if (!rgba_dev || iterations <= 0) return fail("pt_preview_rgba8_device: bad argument");
+  HIP_OK(hipSetDevice(g.device));
+  ptk::launch_preview(g.stream, g.N, iterations, g.d_image, reinterpret_cast<uchar4*>(rgba_dev));
+  HIP_OK(hipStreamSynchronize(g.stream));
+  return 0;
+}
+
+int pt_get_stats(PtStats* out) {
+  if (!g.live) return fail("pt_get_stats: pt_init has not been called");
+  if (!out) return fail("pt_get_stats: null");
+  if (pt_sync()) return -1;
+  std::memset(out, 0, sizeof(*out));
+  unsigned long long st[PT_MAX_DEPTH];
+  HIP_OK(hipMemcpy(st, g.d_stats, sizeof(st), hipMemcpyDeviceToHost));
+  for (int d = 0; d < PT_MAX_DEPTH; ++d) out->live_rays[d] = (int64_t)st[d];
+  out->samples = g.samples;
+  out->intersect_launches = g.isect_launches;
+  out->intersect_ms = g.isect_ms;
+  out->render_ms = g.render_ms;
+  out->num_cus = g.num_cus;
+  out->grid_blocks = g.grid;
+  out->num_queues = g.qs.Q;
+  out->iters_per_batch = g.K;
+  out->device_bytes = g.device_bytes;
+  return 0;
+}
+
+int pt_reset_stats(void) {
+  if (!g.live) return fail("pt_reset_stats: pt_init has not been called");
+  if (pt_sync()) return -1;
+  HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));
+  g.samples = 0;
+  g.isect_ms = g.render_ms = 0;
+  g.isect_launches = 0;
+  return 0;
+}
+
+// ---- stage entry points (tests) ------------------------------------------------
+
+int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
+  if (!g.live) return fail("pt_stage_generate: pt_init has not been called");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(g.device));
+  Scratch sc;
+  ptd::Queues qs = single_queue(n);
+  ptd::PathBuf pb{};
+  pb.stride = qs.cap;
+  pb.o = sc.get<float>(3 * (size_t)qs.cap);
+  pb.d = sc.get<float>(3 * (size_t)qs.cap);
+  pb.c = sc.get<float>(3 * (size_t)qs.cap);
+  pb.slot = sc.get<int32_t>(qs.cap);
+  int32_t* cnt = sc.get<int32_t>(16);
+  if (!pb.o || !pb.d || !pb.c || !pb.slot || !cnt) return fail("pt_stage_generate: out of device memory");
+  ptk::BatchInfo b{};
+  b.iter_first = 1, b.K = 1, b.N = n, b.pixel_begin = pix_begin, b.trace_depth = g.depth;
+  ptk::launch_generate(g.stream, g.grid, g.dcam, b, qs, pb, cnt);
+  HIP_OK(hipStreamSynchronize(g.stream));
+  for (int c = 0; c < 3; ++c) {
+    HIP_OK(hipMemcpy(origin + (size_t)c * n, pb.o + (size_t)c * qs.cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(dir + (size_t)c * n, pb.d + (size_t)c * qs.cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, float* normal, int32_t* material,
+                       float* point) {
+  if (!g.live) return fail("pt_stage_intersect: pt_init has not been called");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(g.device));
+  Scratch sc;
+  ptd::Queues qs = single_queue(n);
+  const size_t cap = qs.cap;
+  ptd::PathBuf pb{};
+  pb.stride = cap;
+  pb.o = sc.get<float>(3 * cap);
+  pb.d = sc.get<float>(3 * cap);
+  ptd::HitBuf hb{};
+  hb.stride = cap;
+  hb.t = sc.get<float>(cap);
+  hb.n = sc.get<float>(3 * cap);
+  hb.mat = sc.get<int32_t>(cap);
+  hb.p = sc.get<float>(3 * cap);
+  int32_t* cnt = sc.get<int32_t>(16);
+  if (!pb.o || !pb.d || !hb.t || !hb.n || !hb.mat || !hb.p || !cnt) return fail("pt_stage_intersect: out of device memory");
+  for (int c = 0; c < 3; ++c) {
+    HIP_OK(hipMemcpy(pb.o + c * cap, origin + (size_t)c * n, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(pb.d + c * cap, dir + (size_t)c * n, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  HIP_OK(hipMemcpy(cnt, &n, 4, hipMemcpyHostToDevice));
+  ptk::launch_intersect(g.stream, g.grid, tables(), qs, cnt, pb, hb);
+  HIP_OK(hipStreamSynchronize(g.stream));
+  HIP_OK(hipMemcpy(t, hb.t, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(material, hb.mat, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (int c = 0; c < 3; ++c) {
+    HIP_OK(hipMemcpy(normal + (size_t)c * n, hb.n + c * cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(point + (size_t)c * n, hb.p + c * cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, const float* t, const float* normal,
+                   const int32_t* material, const float* point, float* origin, float* dir, float* color,
+                   int32_t* alive) {
+  if (!g.live) return fail("pt_stage_shade: pt_init has not been called");
+  if (n <= 0) return 0;
+  if (depth < 0 || depth >= g.depth) return fail("pt_stage_shade: depth %d outside [0,%d)", depth, g.depth);
+  for (int i = 0; i < n; ++i)
+    if (t[i] >= 0.0f && (material[i] < 0 || material[i] >= (int)g.mats.size()))
+      return fail("pt_stage_shade: material id %d out of range at %d", material[i], i);
+  HIP_OK(hipSetDevice(g.device));
+  Scratch sc;
+  const size_t cap = n;
+  ptd::PathBuf pb{};
+  pb.stride = cap;
+  pb.o = sc.get<float>(3 * cap);
+  pb.d = sc.get<float>(3 * cap);
+  pb.c = sc.get<float>(3 * cap);
+  ptd::HitBuf hb{};
+  hb.stride = cap;
+  hb.t = sc.get<float>(cap);
+  hb.n = sc.get<float>(3 * cap);
+  hb.mat = sc.get<int32_t>(cap);
+  hb.p = sc.get<float>(3 * cap);
+  int32_t* d_iter = sc.get<int32_t>(cap);
+  int32_t* d_pix = sc.get<int32_t>(cap);
+  int32_t* d_alive = sc.get<int32_t>(cap);
+  if (!pb.o || !pb.d || !pb.c || !hb.t || !hb.n || !hb.mat || !hb.p || !d_iter || !d_pix || !d_alive)
+    return fail("pt_stage_shade: out of device memory");
+  const size_t b1 = (size_t)n * 4, b3 = 3 * b1;
+  HIP_OK(hipMemcpy(pb.o, origin, b3, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(pb.d, dir, b3, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(pb.c, color, b3, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(hb.t, t, b1, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(hb.n, normal, b3, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(hb.mat, material, b1, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(hb.p, point, b3, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_iter, iter, b1, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_pix, pixel, b1, hipMemcpyHostToDevice));
+  ptk::launch_shade_stage(g.stream, tables(), g.depth, depth, n, d_iter, d_pix, hb, pb, d_alive);
+  HIP_OK(hipStreamSynchronize(g.stream));
+  HIP_OK(hipMemcpy(origin, pb.o, b3, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(dir, pb.d, b3, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(color, pb.c, b3, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(alive, d_alive, b1, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// pt_device.h — device-side data layout of the MI355X wavefront path tracer.
+//
+// Everything the kernels stream is structure-of-arrays with 4-byte scalars so
+// that a wave64 access is one contiguous 256-B run per plane (the reference's
+// PathSegment is 44-B AoS and ShadeableIntersection 40-B AoS,
+// src/sceneStructs.h:69-83).  Scene tables are tiny, read-only, and staged into LDS.
+#pragma once
+#include <stdint.h>
+
+namespace ptd {
+
+// BVH node, 32 B = two ds_read_b128.  The reference stores 36-B nodes with explicit
+// left/right links and walks them with a 64-entry per-thread stack, pushing left
+// then right, i.e. visiting right-subtree first (src/pathtrace.cu:28-32,302-324).
+// That visiting order does not depend on the ray, so the tree is re-emitted in
+// exactly that order (node, right subtree, left subtree) with a "skip" link to the
+// first node after the subtree: traversal is then a stackless forward scan that
+// performs the same node tests and the same leaf tests in the same order.
+struct Node {
+  float bmin[3];
+  float bmax[3];
+  int32_t skip;  // index of the next node when this subtree is not entered
+  int32_t geom;  // >= 0: leaf, index into the geom table; -1: inner node
+};
+static_assert(sizeof(Node) == 32, "Node must be 32 B");
+
+// Geometry record, 160 B.  Only rows 0..2 of each matrix are ever used
+// (multiplyMV returns vec3, src/intersections.h:34-36), stored m[c*3+r] == glm m[c][r].
+struct Geom {
+  float inv[12];   // inverseTransform
+  float xf[12];    // transform
+  float invT[12];  // invTranspose
+  int32_t type;    // 0 sphere, 1 cube (sceneStructs.h:10-13)
+  int32_t material;
+  int32_t pad[2];
+};
+static_assert(sizeof(Geom) == 160, "Geom must be 160 B");
+
+// The five Material fields shading reads (sceneStructs.h:38-48), 48 B.
+struct Mat {
+  float color[3];
+  float spec[3];
+  float reflective;
+  float refractive;
+  float emittance;
+  float pad[3];
+};
+static_assert(sizeof(Mat) == 48, "Mat must be 48 B");
+
+struct Camera {
+  int32_t res_x, res_y;
+  float pos[3], view[3], up[3], right[3];
+  float pl_x, pl_y;
+};
+
+// Ray / path state planes.  A path occupies the same index in every plane.
+struct PathBuf {
+  float* o;      // [3][stride] origin
+  float* d;      // [3][stride] direction
+  float* c;      // [3][stride] throughput colour
+  int32_t* slot; // [stride]    sample id inside the batch: k*N + p  (k = iteration in batch, p = tile pixel)
+  int64_t stride;
+};
+// Hit records (the 32 live bytes of ShadeableIntersection).
+struct HitBuf {
+  float* t;        // [stride]
+  float* n;        // [3][stride]
+  int32_t* mat;    // [stride]
+  float* p;        // [3][stride]
+  int64_t stride;
+};
+
+// Work distribution.  Paths live in Q independent queues of capacity `cap`
+// (queue q owns indices [q*cap, (q+1)*cap) of every plane).  The persistent grid has
+// W waves; wave w serves queue w % Q together with the other W/Q - 1 waves of that
+// queue, taking 64-path groups round-robin.  Survivors of a shading pass are appended
+// to the same queue of the other PathBuf through one atomicAdd per wave on the
+// queue's counter, so counters are spread over Q cache lines.
+struct Queues {
+  int32_t Q;
+  int32_t cap;
+  int32_t W;            // total waves in the grid (multiple of Q)
+  int32_t cnt_stride;   // ints between consecutive queue counters (64-B padding)
+};
+
+}  // namespace ptd

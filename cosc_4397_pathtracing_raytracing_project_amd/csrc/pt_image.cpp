@@ -1,0 +1,118 @@
+// pt_image.cpp — image output of the MI355X path tracer: what the reference's
+// saveImage() (src/main.cpp:86-107) + image::savePNG (src/image.cpp:22-39) produce,
+// without stb: a self-contained PNG encoder (zlib "stored" deflate blocks) and a
+// PFM writer for lossless float output.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+
+namespace {
+
+uint32_t crc_table[256];
+bool crc_ready = false;
+uint32_t crc32(const uint8_t* p, size_t n, uint32_t c = 0xffffffffu) {
+  if (!crc_ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t v = i;
+      for (int k = 0; k < 8; ++k) v = (v & 1) ? 0xedb88320u ^ (v >> 1) : v >> 1;
+      crc_table[i] = v;
+    }
+    crc_ready = true;
+  }
+  for (size_t i = 0; i < n; ++i) c = crc_table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+  return c;
+}
+void be32(std::vector<uint8_t>& v, uint32_t x) {
+  v.push_back(x >> 24), v.push_back(x >> 16), v.push_back(x >> 8), v.push_back(x);
+}
+void chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
+  be32(out, (uint32_t)data.size());
+  std::vector<uint8_t> td(type, type + 4);
+  td.insert(td.end(), data.begin(), data.end());
+  out.insert(out.end(), td.begin(), td.end());
+  be32(out, crc32(td.data(), td.size()) ^ 0xffffffffu);
+}
+// zlib stream of stored (uncompressed) deflate blocks
+std::vector<uint8_t> zstore(const std::vector<uint8_t>& raw) {
+  std::vector<uint8_t> z = {0x78, 0x01};
+  size_t pos = 0;
+  do {
+    const size_t n = std::min<size_t>(65535, raw.size() - pos);
+    const bool last = pos + n == raw.size();
+    z.push_back(last ? 1 : 0);
+    z.push_back(n & 0xff), z.push_back(n >> 8);
+    z.push_back(~n & 0xff), z.push_back((~n >> 8) & 0xff);
+    z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+    pos += n;
+  } while (pos < raw.size());
+  uint32_t a = 1, b = 0;
+  for (uint8_t c : raw) {
+    a = (a + c) % 65521u;
+    b = (b + a) % 65521u;
+  }
+  be32(z, (b << 16) | a);
+  return z;
+}
+// clamp(pix, 0, 1) * 255 truncated to u8, as image.cpp:26-30 (glm::clamp = min(max(x,0),1))
+uint8_t to_u8(float v) {
+  float m = v > 0.0f ? v : 0.0f;
+  m = m < 1.0f ? m : 1.0f;
+  return (uint8_t)(m * 255.f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_save_png(const char* path, const float* rgb_sum, int w, int h, float samples) {
+  if (!path || !rgb_sum || w <= 0 || h <= 0) return -1;
+  std::vector<uint8_t> raw;
+  raw.reserve((size_t)h * (3 * (size_t)w + 1));
+  for (int y = 0; y < h; ++y) {
+    raw.push_back(0);  // filter: none
+    for (int x = 0; x < w; ++x) {
+      // saveImage(): img.setPixel(width - 1 - x, y, pix / samples) — output column x shows source column w-1-x
+      const float* s = rgb_sum + 3 * ((size_t)(w - 1 - x) + (size_t)y * w);
+      raw.push_back(to_u8(s[0] / samples));
+      raw.push_back(to_u8(s[1] / samples));
+      raw.push_back(to_u8(s[2] / samples));
+    }
+  }
+  std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  std::vector<uint8_t> ihdr;
+  be32(ihdr, (uint32_t)w), be32(ihdr, (uint32_t)h);
+  ihdr.push_back(8), ihdr.push_back(2), ihdr.push_back(0), ihdr.push_back(0), ihdr.push_back(0);
+  chunk(out, "IHDR", ihdr);
+  chunk(out, "IDAT", zstore(raw));
+  chunk(out, "IEND", {});
+  FILE* f = fopen(path, "wb");
+  if (!f) return -1;
+  const size_t n = fwrite(out.data(), 1, out.size(), f);
+  fclose(f);
+  return n == out.size() ? 0 : -1;
+}
+
+// Little-endian PFM, rows bottom-to-top per the format; raw orientation (no x mirror),
+// averaged radiance — the loss-free companion to the PNG for PSNR work.
+int pt_save_pfm(const char* path, const float* rgb_sum, int w, int h, float samples) {
+  if (!path || !rgb_sum || w <= 0 || h <= 0) return -1;
+  FILE* f = fopen(path, "wb");
+  if (!f) return -1;
+  fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
+  std::vector<float> row(3 * (size_t)w);
+  for (int y = h - 1; y >= 0; --y) {
+    for (size_t i = 0; i < row.size(); ++i) row[i] = rgb_sum[(size_t)y * w * 3 + i] / samples;
+    if (fwrite(row.data(), sizeof(float), row.size(), f) != row.size()) {
+      fclose(f);
+      return -1;
+    }
+  }
+  fclose(f);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// pt_kernels.h — launch interface of the HIP kernels (pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pt_device.h"
+
+namespace ptk {
+
+constexpr int kBlock = 256;        // 4 wave64 per workgroup
+constexpr int kWavesPerBlock = 4;
+constexpr int kLdsTableBytes = 64 * 1024;  // scene tables are staged in LDS up to this size
+
+struct SceneTables {
+  const ptd::Node* nodes;  // threaded DFS order
+  int32_t num_nodes;
+  const ptd::Geom* geoms;
+  int32_t num_geoms;
+  const ptd::Mat* mats;
+  int32_t num_mats;
+};
+
+struct BatchInfo {
+  int32_t iter_first;   // iteration number (1-based) of sample plane k = 0
+  int32_t K;            // iterations in this batch
+  int32_t N;            // pixels in the tile
+  int32_t pixel_begin;  // global index of tile pixel 0
+  int32_t trace_depth;
+};
+
+// generateRayFromCamera for all K*N samples of a batch, straight into the queues.
+// Also writes the queue fill counts cnt0[q*cnt_stride].
+void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
+                     ptd::PathBuf out, int32_t* cnt0);
+// computeIntersections over the live paths of every queue.
+void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
+                      ptd::PathBuf paths, ptd::HitBuf hits);
+// shadeAndExtendRays + compaction + retirement.
+void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
+                  const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
+                  float* final_rgb /* [3][K*N] planes */);
+// finalGather: image[p] += final[0][p] + final[1][p] + ... in iteration order.
+void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, float* image_rgb /* [N][3] */);
+// live-ray bookkeeping: stats[d] += sum_q cnt[d][q]
+void launch_count_stats(hipStream_t s, const ptd::Queues& qs, const int32_t* cnt, int depth_count,
+                        unsigned long long* stats);
+// sendImageToPBO (pathtrace.cu:250-268)
+void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba);
+
+// Stage helper for tests: one shading step on n explicit paths (single queue, no compaction):
+// writes alive flags and in-place o/d/color.
+void launch_shade_stage(hipStream_t s, const SceneTables& sc, int trace_depth, int depth, int n, const int32_t* iter,
+                        const int32_t* pixel, ptd::HitBuf hits, ptd::PathBuf paths, int32_t* alive);
+
+}  // namespace ptk

@@ -1,0 +1,572 @@
+// pt_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the wavefront
+// path tracer.  One persistent grid per stage; SoA path state; BVH + geometry +
+// material tables staged in LDS; wave-level ballot/mbcnt compaction.
+//
+// What each kernel restates (reference paths relative to its repo root):
+//   k_generate   generateRayFromCamera   src/pathtrace.cu:270-286
+//   k_intersect  computeIntersections    src/pathtrace.cu:288-333, intersectAABB :113-128,
+//                box/sphereIntersectionTest src/intersections.h:48-144
+//   k_shade      shadeAndExtendRays      src/pathtrace.cu:336-437 (+ helpers :216-242,
+//                RNG :203-207, utilhash intersections.h:12-20) fused with the retirement
+//                rule of SURVEY.md §8a and the compaction the reference never had
+//   k_gather     finalGather             src/pathtrace.cu:439-444
+//   k_preview    sendImageToPBO          src/pathtrace.cu:250-268
+//
+// Arithmetic contract: compiled with -ffp-contract=off; every float operation is
+// written in the order GLM 0.9.6 / the reference evaluate it, divisions and square
+// roots are IEEE (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), and
+// sin/cos/acos come from pt_portable_math.h, so results are bit-identical to
+// oracle/pt_oracle.cpp in PORTABLE mode.  No MFMA: there is no dense contraction here.
+#include "pt_kernels.h"
+
+#include <float.h>
+
+#include "pt_portable_math.h"
+
+namespace ptk {
+namespace {
+
+#define PT_DEV __device__ __forceinline__
+
+struct f3 {
+  float x, y, z;
+};
+PT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+PT_DEV f3 add(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV f3 sub(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV f3 mul(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV f3 scl(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PT_DEV f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
+PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+PT_DEV f3 cross(f3 x, f3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+PT_DEV f3 normalize(f3 v) { return scl(v, 1.0f / __builtin_sqrtf(dot(v, v))); }
+PT_DEV float length(f3 v) { return __builtin_sqrtf(dot(v, v)); }
+
+// vec3(m * vec4(v, w)) in GLM order: (m0*v0 + m1*v1) + (m2*v2 + m3*w); m is [c*3+r].
+PT_DEV f3 mulMV(const float* m, f3 v, float w) {
+  f3 r;
+  r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * w);
+  r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * w);
+  r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11] * w);
+  return r;
+}
+
+PT_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+
+// ───────────────────────────── RNG ──────────────────────────────────────────
+PT_DEV uint32_t utilhash(uint32_t a) {  // intersections.h:12-20
+  a = (a + 0x7ed55d16u) + (a << 12);
+  a = (a ^ 0xc761c23cu) ^ (a >> 19);
+  a = (a + 0x165667b1u) + (a << 5);
+  a = (a + 0xd3a2646cu) ^ (a << 9);
+  a = (a + 0xfd7046c5u) + (a << 3);
+  a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+  return a;
+}
+// thrust::minstd_rand (a = 48271, m = 2^31 - 1) with Mersenne folding instead of %.
+struct MinStd {
+  uint32_t x;
+  PT_DEV explicit MinStd(uint32_t s) {
+    uint32_t r = (s & 0x7fffffffu) + (s >> 31);  // s mod (2^31-1)
+    if (r >= 0x7fffffffu) r -= 0x7fffffffu;
+    x = r == 0u ? 1u : r;
+  }
+  PT_DEV uint32_t next() {
+    uint64_t p = (uint64_t)x * 48271u;  // < 2^47
+    uint32_t r = (uint32_t)(p & 0x7fffffffu) + (uint32_t)(p >> 31);
+    if (r >= 0x7fffffffu) r -= 0x7fffffffu;
+    x = r;
+    return r;
+  }
+  // uniform_real_distribution<float>(0,1): float(x - 1) / 2^31 (exact scaling)
+  PT_DEV float u01() { return (float)(next() - 1u) * 4.656612873077392578125e-10f; }
+};
+PT_DEV uint32_t seed_hash(int iter, int index, int depth) {  // pathtrace.cu:203-207
+  return utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter) ^ utilhash((uint32_t)index);
+}
+
+// ───────────────────────────── LDS staging ─────────────────────────────────
+// Copies `bytes` (multiple of 16) from global to LDS with 16-B accesses.
+PT_DEV void stage16(void* lds, const void* g, int bytes) {
+  const float4* src = reinterpret_cast<const float4*>(g);
+  float4* dst = reinterpret_cast<float4*>(lds);
+  for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) dst[i] = src[i];
+}
+
+// ───────────────────────────── generate ────────────────────────────────────
+__global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo b, ptd::Queues qs, ptd::PathBuf out,
+                                                     int32_t* __restrict__ cnt0) {
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const long long total = (long long)b.K * b.N;
+  const long long chunks = (total + 63) / 64;           // 64-sample chunks, dealt round-robin to queues
+  const long long my_chunks = (chunks - q + qs.Q - 1) / qs.Q;  // chunks q, q+Q, ...
+  if (r == 0 && lane == 0) {
+    long long n = 0;
+    if (my_chunks > 0) {
+      const long long last = q + (my_chunks - 1) * qs.Q;  // global id of my last chunk
+      n = (my_chunks - 1) * 64 + (last == chunks - 1 ? total - last * 64 : 64);
+    }
+    cnt0[(size_t)q * qs.cnt_stride] = (int32_t)n;
+  }
+  const int64_t S = out.stride;
+  for (long long j = r; j < my_chunks; j += wq) {
+    const long long gid = (j * qs.Q + q) * 64 + lane;
+    if (gid < total) {
+      const int k = (int)(gid / b.N);
+      const int p = (int)(gid - (long long)k * b.N) + b.pixel_begin;  // global pixel index
+      const int x = p % cam.res_x, y = p / cam.res_x;
+      // dir = normalize(view - right*pl.x*(x - W/2) - up*pl.y*(y - H/2))
+      const float fx = (float)x - cam.res_x * 0.5f;
+      const float fy = (float)y - cam.res_y * 0.5f;
+      f3 view = mk(cam.view[0], cam.view[1], cam.view[2]);
+      f3 a = scl(scl(mk(cam.right[0], cam.right[1], cam.right[2]), cam.pl_x), fx);
+      f3 c = scl(scl(mk(cam.up[0], cam.up[1], cam.up[2]), cam.pl_y), fy);
+      f3 d = normalize(sub(sub(view, a), c));
+      const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
+      out.o[at] = cam.pos[0], out.o[S + at] = cam.pos[1], out.o[2 * S + at] = cam.pos[2];
+      out.d[at] = d.x, out.d[S + at] = d.y, out.d[2 * S + at] = d.z;
+      out.c[at] = 1.0f, out.c[S + at] = 1.0f, out.c[2 * S + at] = 1.0f;
+      out.slot[at] = (int32_t)gid;
+    }
+  }
+}
+
+// ───────────────────────────── intersect ───────────────────────────────────
+struct HitRec {
+  float t;
+  f3 n;
+  f3 p;
+  int geom;
+};
+
+// Primitive test shared by cube and sphere: the object-space transform of the ray and
+// the world-space reconstruction of point/normal/distance are common code; only the
+// middle (slab vs quadratic) diverges.  Returns t (-1 = no hit).
+PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& point, f3& normal) {
+  const f3 qo = mulMV(G->inv, ro_w, 1.0f);
+  const f3 qd = normalize(mulMV(G->inv, rd_w, 0.0f));
+  float t;
+  f3 nobj;
+  bool flip = false;
+  if (G->type == 1) {
+    // boxIntersectionTest, intersections.h:48-90
+    float tmin = -1e38f, tmax = 1e38f;
+    f3 tmin_n = mk(0.f, 0.f, 0.f), tmax_n = mk(0.f, 0.f, 0.f);
+    const float qdv[3] = {qd.x, qd.y, qd.z};
+    const float qov[3] = {qo.x, qo.y, qo.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float t1 = (-0.5f - qov[a]) / qdv[a];
+      const float t2 = (+0.5f - qov[a]) / qdv[a];
+      const float ta = t1 < t2 ? t1 : t2;  // glm::min
+      const float tb = t1 > t2 ? t1 : t2;  // glm::max
+      const float s = t2 < t1 ? 1.0f : -1.0f;
+      const f3 n = mk(a == 0 ? s : 0.f, a == 1 ? s : 0.f, a == 2 ? s : 0.f);
+      if (ta > 0.f && ta > tmin) {
+        tmin = ta;
+        tmin_n = n;
+      }
+      if (tb < tmax) {
+        tmax = tb;
+        tmax_n = n;
+      }
+    }
+    if (!(tmax >= tmin && tmax > 0.f)) return -1.0f;
+    if (tmin <= 0.f) {
+      tmin = tmax;
+      tmin_n = tmax_n;
+    }
+    t = tmin;
+    nobj = tmin_n;
+  } else {
+    // sphereIntersectionTest, intersections.h:102-144 (radius .5 → powf(.5,2) = .25)
+    const float vDotDirection = dot(qo, qd);
+    const float radicand = vDotDirection * vDotDirection - (dot(qo, qo) - 0.25f);
+    if (radicand < 0.f) return -1.0f;
+    const float squareRoot = __builtin_sqrtf(radicand);
+    const float firstTerm = -vDotDirection;
+    const float t1 = firstTerm + squareRoot;
+    const float t2 = firstTerm - squareRoot;
+    if (t1 < 0.f && t2 < 0.f) return -1.0f;
+    if (t1 > 0.f && t2 > 0.f) {
+      t = t2 < t1 ? t2 : t1;  // min(t1, t2)
+    } else {
+      t = t1 < t2 ? t2 : t1;  // max(t1, t2)
+      flip = true;            // !outside → normal negated
+    }
+    nobj = mk(0.f, 0.f, 0.f);
+  }
+  // getPointOnRay (intersections.h:27-29): origin + (t - .0001f) * normalize(direction)
+  const f3 objp = add(qo, scl(normalize(qd), t - .0001f));
+  if (G->type != 1) nobj = objp;
+  point = mulMV(G->xf, objp, 1.0f);
+  normal = normalize(mulMV(G->invT, nobj, 0.0f));
+  if (flip) normal = neg(normal);
+  return length(sub(ro_w, point));
+}
+
+// Closest hit for one ray; `nodes`/`geoms` may point to LDS or global memory.
+PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const ptd::Geom* __restrict__ geoms, f3 o, f3 d) {
+  HitRec h;
+  h.t = FLT_MAX;
+  h.geom = -1;
+  h.n = mk(0.f, 0.f, 0.f);
+  h.p = mk(0.f, 0.f, 0.f);
+  // intersectAABB recomputes 1/dir per node (pathtrace.cu:116); same value every time.
+  const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+  const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
+  int i = 0;
+  while (true) {
+    int g = -1;
+    // forward scan until this lane reaches a leaf whose box it enters (or the end);
+    // the primitive test is postponed so that lanes of the wave run it together.
+    while (i < num_nodes) {
+      const float4 A = reinterpret_cast<const float4*>(nodes)[2 * i];      // bmin.xyz, bmax.x
+      const float4 B = reinterpret_cast<const float4*>(nodes)[2 * i + 1];  // bmax.yz, skip, geom
+      // t0 = (min - o) * invD, t1 = (max - o) * invD, swapped when invD < 0
+      const float t0x = ((sx ? A.w : A.x) - o.x) * ix;
+      const float t1x = ((sx ? A.x : A.w) - o.x) * ix;
+      const float t0y = ((sy ? B.x : A.y) - o.y) * iy;
+      const float t1y = ((sy ? A.y : B.x) - o.y) * iy;
+      const float t0z = ((sz ? B.y : A.z) - o.z) * iz;
+      const float t1z = ((sz ? A.z : B.y) - o.z) * iz;
+      const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
+      const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
+      // The reference returns false at the first axis with tmax <= tmin; tmin only grows
+      // and tmax only shrinks, so that is equivalent to one test after the third axis.
+      if (tmax <= tmin) {
+        i = __float_as_int(B.z);
+        continue;
+      }
+      i = i + 1;
+      const int leaf = __float_as_int(B.w);
+      if (leaf >= 0) {
+        g = leaf;
+        break;
+      }
+    }
+    if (g < 0) break;
+    f3 pt, nrm;
+    const float t = geom_test(geoms + g, o, d, pt, nrm);
+    if (t > 0.f && t < h.t) {  // strict <: first found wins ties (pathtrace.cu:314)
+      h.t = t;
+      h.geom = g;
+      h.p = pt;
+      h.n = nrm;
+    }
+  }
+  return h;
+}
+
+template <bool TABLES_IN_LDS>
+__global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queues qs, const int32_t* __restrict__ cnt_in,
+                                                      ptd::PathBuf paths, ptd::HitBuf hits) {
+  extern __shared__ float4 lds_raw[];
+  const ptd::Node* nodes = sc.nodes;
+  const ptd::Geom* geoms = sc.geoms;
+  if (TABLES_IN_LDS) {
+    char* base = reinterpret_cast<char*>(lds_raw);
+    stage16(base, sc.nodes, sc.num_nodes * (int)sizeof(ptd::Node));
+    stage16(base + sc.num_nodes * sizeof(ptd::Node), sc.geoms, sc.num_geoms * (int)sizeof(ptd::Geom));
+    __syncthreads();
+    nodes = reinterpret_cast<const ptd::Node*>(base);
+    geoms = reinterpret_cast<const ptd::Geom*>(base + sc.num_nodes * sizeof(ptd::Node));
+  }
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
+  const int64_t S = paths.stride, HS = hits.stride;
+  for (int j = r; j * 64 < n_q; j += wq) {
+    const int i = j * 64 + lane;
+    if (i < n_q) {
+      const int64_t at = (int64_t)q * qs.cap + i;
+      const f3 o = mk(paths.o[at], paths.o[S + at], paths.o[2 * S + at]);
+      const f3 d = mk(paths.d[at], paths.d[S + at], paths.d[2 * S + at]);
+      const HitRec h = trace(nodes, sc.num_nodes, geoms, o, d);
+      const bool hit = h.geom >= 0;
+      // record layout of the reference after its per-depth memset (pathtrace.cu:562):
+      // miss → t = -1 and zeros elsewhere.
+      hits.t[at] = hit ? h.t : -1.0f;
+      hits.n[at] = h.n.x, hits.n[HS + at] = h.n.y, hits.n[2 * HS + at] = h.n.z;
+      hits.mat[at] = hit ? geoms[h.geom].material : 0;
+      hits.p[at] = h.p.x, hits.p[HS + at] = h.p.y, hits.p[2 * HS + at] = h.p.z;
+    }
+  }
+}
+
+// ───────────────────────────── shade ───────────────────────────────────────
+PT_DEV void local_frame(f3 n, f3& tangent, f3& bitangent) {  // pathtrace.cu:216-223
+  if (__builtin_fabsf(n.x) > __builtin_fabsf(n.y)) tangent = normalize(mk(n.z, 0.f, -n.x));
+  else tangent = normalize(mk(0.f, -n.z, n.y));
+  bitangent = cross(n, tangent);
+}
+PT_DEV f3 sky_factor(f3 dir) {  // pathtrace.cu:360-362: skyColor * 0.5f
+  const float t = 0.5f * (dir.y + 1.0f);
+  const float w = (1.0f - t) * 1.0f;
+  return scl(mk(w + t * 0.5f, w + t * 0.7f, w + t * 1.0f), 0.5f);
+}
+
+struct ShadeIO {
+  f3 o, d, c;
+  bool alive;
+};
+// One thread of shadeAndExtendRays for a LIVE path (remainingBounces > 0 is implied:
+// a live path at depth d has exactly trace_depth - d bounces left).  On return
+// `alive == false` means the path retires with colour s.c; for a miss the sky factor
+// has been applied (trace_depth - depth) times, which is what the reference's repeated
+// passes over dead paths do (pathtrace.cu:356-366).
+PT_DEV void shade_core(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, int iter, int pixel, float ht,
+                       f3 hn, int hmat, f3 hp, ShadeIO& s) {
+  if (ht < 0.0f) {
+    const f3 sky = sky_factor(s.d);
+    for (int k = depth; k < trace_depth; ++k) s.c = mul(s.c, sky);
+    s.alive = false;
+    return;
+  }
+  MinStd rng(seed_hash(iter, pixel, depth));
+  const ptd::Mat* m = mats + hmat;
+  const f3 mcolor = mk(m->color[0], m->color[1], m->color[2]);
+  if (m->emittance > 0.0f) {
+    s.c = mul(s.c, scl(mcolor, m->emittance));
+    s.alive = false;
+    return;
+  }
+  if (depth > 3) {  // Russian roulette
+    const float q = __builtin_fmaxf(mcolor.x, __builtin_fmaxf(mcolor.y, mcolor.z));
+    if (rng.u01() > q) {
+      s.alive = false;
+      return;
+    }
+    s.c = mk(s.c.x / q, s.c.y / q, s.c.z / q);
+  }
+  const float reflectivity = m->reflective;
+  const float roughness = 1.0f - m->refractive;
+  f3 ndir;
+  if (reflectivity > 0.0f && rng.u01() < reflectivity) {
+    // reflect(): incident - 2*dot(incident, normal)*normal
+    f3 rdir = sub(s.d, scl(hn, 2.0f * dot(s.d, hn)));
+    if (roughness > 0.0f) {
+      f3 tangent, bitangent;
+      local_frame(rdir, tangent, bitangent);
+      // M_PI is double in the reference: these products are evaluated in double
+      const float angle = (float)((double)(roughness * rng.u01()) * 3.14159265358979323846 * (double)0.5f);
+      const float sa = ptmath::sinf32(angle);
+      const float x = (float)((double)sa * ptmath::cos64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
+      const float y = ptmath::cosf32(angle);
+      const float z = (float)((double)sa * ptmath::sin64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
+      rdir = normalize(add(add(scl(tangent, x), scl(rdir, y)), scl(bitangent, z)));
+    }
+    ndir = rdir;
+    s.c = mul(s.c, mk(m->spec[0], m->spec[1], m->spec[2]));
+  } else {
+    const float u1 = rng.u01();
+    const float u2 = rng.u01();
+    f3 tangent, bitangent;
+    local_frame(hn, tangent, bitangent);
+    const float theta = ptmath::acosf32(__builtin_sqrtf(1.0f - u1));
+    const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)u2);
+    const float st = ptmath::sinf32(theta);
+    const float x = st * ptmath::cosf32(phi);
+    const float y = ptmath::cosf32(theta);
+    const float z = st * ptmath::sinf32(phi);
+    ndir = normalize(add(add(scl(tangent, x), scl(hn, y)), scl(bitangent, z)));
+    s.c = mul(s.c, mcolor);
+  }
+  s.o = add(hp, scl(hn, 0.001f));
+  s.d = ndir;
+  // remainingBounces-- : the path survives unless this was its last allowed bounce
+  s.alive = (depth + 1) < trace_depth;
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
+                                                  const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
+                                                  ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
+                                                  float* __restrict__ final_rgb) {
+  extern __shared__ float4 lds_raw[];
+  stage16(lds_raw, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
+  __syncthreads();
+  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds_raw);
+
+  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
+  const int64_t S = in.stride, HS = hits.stride, OS = out.stride;
+  const int64_t FS = (int64_t)b.K * b.N;
+  for (int j = r; j * 64 < n_q; j += wq) {
+    const int i = j * 64 + lane;
+    const bool valid = i < n_q;
+    ShadeIO s;
+    s.alive = false;
+    int slot = 0;
+    if (valid) {
+      const int64_t at = (int64_t)q * qs.cap + i;
+      slot = in.slot[at];
+      const int k = slot / b.N;
+      const int p = slot - k * b.N;
+      const float ht = hits.t[at];
+      const f3 hn = mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]);
+      const int hmat = hits.mat[at];
+      const f3 hp = mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]);
+      s.o = mk(0.f, 0.f, 0.f);
+      s.d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
+      s.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
+      shade_core(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, ht, hn, hmat, hp, s);
+      if (!s.alive) {  // retire: exactly one write per (iteration, pixel)
+        final_rgb[slot] = s.c.x, final_rgb[FS + slot] = s.c.y, final_rgb[2 * FS + slot] = s.c.z;
+      }
+    }
+    // wave-level compaction: ballot + prefix popcount, one atomic per wave
+    const unsigned long long live = __ballot(valid && s.alive);
+    if (live) {
+      const int nlive = __popcll(live);
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0));
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&cnt_out[(size_t)q * qs.cnt_stride], nlive);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (valid && s.alive) {
+        const int64_t to = (int64_t)q * qs.cap + base + rank;
+        out.o[to] = s.o.x, out.o[OS + to] = s.o.y, out.o[2 * OS + to] = s.o.z;
+        out.d[to] = s.d.x, out.d[OS + to] = s.d.y, out.d[2 * OS + to] = s.d.z;
+        out.c[to] = s.c.x, out.c[OS + to] = s.c.y, out.c[2 * OS + to] = s.c.z;
+        out.slot[to] = slot;
+      }
+    }
+  }
+}
+
+// test-only stage: explicit (iter, pixel) per path, in-place, no compaction
+__global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trace_depth, int depth, int n,
+                                                        const int32_t* __restrict__ iter,
+                                                        const int32_t* __restrict__ pixel, ptd::HitBuf hits,
+                                                        ptd::PathBuf paths, int32_t* __restrict__ alive) {
+  extern __shared__ float4 lds_raw[];
+  stage16(lds_raw, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
+  __syncthreads();
+  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds_raw);
+  const int64_t S = paths.stride, HS = hits.stride;
+  for (int at = blockIdx.x * blockDim.x + threadIdx.x; at < n; at += gridDim.x * blockDim.x) {
+    ShadeIO s;
+    s.o = mk(paths.o[at], paths.o[S + at], paths.o[2 * S + at]);
+    s.d = mk(paths.d[at], paths.d[S + at], paths.d[2 * S + at]);
+    s.c = mk(paths.c[at], paths.c[S + at], paths.c[2 * S + at]);
+    s.alive = false;
+    shade_core(mats, trace_depth, depth, iter[at], pixel[at], hits.t[at],
+               mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]), hits.mat[at],
+               mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]), s);
+    paths.o[at] = s.o.x, paths.o[S + at] = s.o.y, paths.o[2 * S + at] = s.o.z;
+    paths.d[at] = s.d.x, paths.d[S + at] = s.d.y, paths.d[2 * S + at] = s.d.z;
+    paths.c[at] = s.c.x, paths.c[S + at] = s.c.y, paths.c[2 * S + at] = s.c.z;
+    alive[at] = s.alive ? 1 : 0;
+  }
+}
+
+// ───────────────────────────── gather / stats / preview ────────────────────
+__global__ __launch_bounds__(kBlock) void k_gather(BatchInfo b, const float* __restrict__ final_rgb,
+                                                   float* __restrict__ image) {
+  const int64_t FS = (int64_t)b.K * b.N;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < b.N; p += gridDim.x * blockDim.x) {
+    float r = image[3 * (int64_t)p], g = image[3 * (int64_t)p + 1], bl = image[3 * (int64_t)p + 2];
+    for (int k = 0; k < b.K; ++k) {  // iteration order, like successive finalGather launches
+      const int64_t s = (int64_t)k * b.N + p;
+      r += final_rgb[s];
+      g += final_rgb[FS + s];
+      bl += final_rgb[2 * FS + s];
+    }
+    image[3 * (int64_t)p] = r, image[3 * (int64_t)p + 1] = g, image[3 * (int64_t)p + 2] = bl;
+  }
+}
+
+__global__ void k_count_stats(ptd::Queues qs, const int32_t* __restrict__ cnt, int depth_count,
+                              unsigned long long* __restrict__ stats) {
+  // one block per depth
+  const int d = blockIdx.x;
+  if (d >= depth_count) return;
+  unsigned long long acc = 0;
+  for (int q = threadIdx.x; q < qs.Q; q += blockDim.x) acc += (unsigned long long)cnt[((size_t)d * qs.Q + q) * qs.cnt_stride];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ unsigned long long part[kWavesPerBlock];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+    stats[d] += t;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_preview(int n, int iterations, const float* __restrict__ image,
+                                                    uchar4* __restrict__ rgba) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const float inv = (float)iterations;
+    float v[3];
+    for (int c = 0; c < 3; ++c) {
+      const float pix = __builtin_powf(image[3 * (int64_t)p + c] / inv, 1.0f / 2.2f);
+      int q = (int)(pix * 255.0f);
+      v[c] = (float)(q < 0 ? 0 : (q > 255 ? 255 : q));
+    }
+    rgba[p] = make_uchar4((unsigned char)v[0], (unsigned char)v[1], (unsigned char)v[2], 0);
+  }
+}
+
+inline int round16(int x) { return (x + 15) & ~15; }
+
+}  // namespace
+
+// ───────────────────────────── launch wrappers ─────────────────────────────
+void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
+                     ptd::PathBuf out, int32_t* cnt0) {
+  hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, cam, b, qs, out, cnt0);
+}
+
+void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
+                      ptd::PathBuf paths, ptd::HitBuf hits) {
+  const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
+  if (bytes <= kLdsTableBytes) {
+    hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), round16(bytes), s, sc, qs, cnt_in, paths, hits);
+  } else {
+    hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, s, sc, qs, cnt_in, paths, hits);
+  }
+}
+
+void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
+                  const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
+                  float* final_rgb) {
+  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat));
+  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
+                     final_rgb);
+}
+
+void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, float* image_rgb) {
+  int grid = (b.N + kBlock - 1) / kBlock;
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlock), 0, s, b, final_rgb, image_rgb);
+}
+
+void launch_count_stats(hipStream_t s, const ptd::Queues& qs, const int32_t* cnt, int depth_count,
+                        unsigned long long* stats) {
+  hipLaunchKernelGGL(k_count_stats, dim3(depth_count), dim3(kBlock), 0, s, qs, cnt, depth_count, stats);
+}
+
+void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba) {
+  int grid = (n + kBlock - 1) / kBlock;
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(k_preview, dim3(grid), dim3(kBlock), 0, s, n, iterations, image_rgb, rgba);
+}
+
+void launch_shade_stage(hipStream_t s, const SceneTables& sc, int trace_depth, int depth, int n, const int32_t* iter,
+                        const int32_t* pixel, ptd::HitBuf hits, ptd::PathBuf paths, int32_t* alive) {
+  int grid = (n + kBlock - 1) / kBlock;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat));
+  hipLaunchKernelGGL(k_shade_stage, dim3(grid), dim3(kBlock), bytes, s, sc, trace_depth, depth, n, iter, pixel, hits,
+                     paths, alive);
+}
+
+}  // namespace ptk

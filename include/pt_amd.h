@@ -1,0 +1,171 @@
+/* pt_amd.h — C ABI of the MI355X-native wavefront path tracer (libpt_amd.so).
+ *
+ * This is the drop-in boundary for the reference's renderer API
+ * (reference: src/pathtrace.h:6-9 — InitDataContainer / pathtraceInit /
+ * pathtraceFree / pathtrace) and for the host-side scene model it consumes
+ * (src/scene.h:20-25, src/sceneStructs.h).  Plain C: pointers, sizes, PODs.
+ * No C++ `Scene`, no GLM and no torch types cross this boundary.
+ * The C++ source-compatible mirror of pathtrace.h lives in
+ * include/pathtrace_amd.hpp; INTEGRATION.md shows the reference-side glue.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; pt_last_error()
+ *     gives the message (the reference prints + exit()s, pathtrace.cu:141-150).
+ *   - matrices are column-major float[16], element [c*4+r] == glm m[c][r].
+ *   - images are float RGB, running SUM over iterations (not the average), in the
+ *     reference's raw orientation (index = x + y*W; saveImage() mirrors x later,
+ *     src/main.cpp:91-97), exactly what pathtrace() leaves in
+ *     scene->state.image (pathtrace.cu:648-651).
+ *   - single caller thread, one global renderer instance (pathtrace.cu:446-456).
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_GEOM_SPHERE 0 /* sceneStructs.h:10-13 */
+#define PT_GEOM_CUBE 1
+
+/* The fields of `Geom` the renderer reads (sceneStructs.h:20-36). */
+typedef struct PtGeom {
+  int32_t type;
+  int32_t materialid;
+  float transform[16];
+  float inverseTransform[16];
+  float invTranspose[16];
+} PtGeom;
+
+/* Same field order and size (44 B) as `Material` (sceneStructs.h:38-48). */
+typedef struct PtMaterial {
+  float color[3];
+  float specular_exponent;
+  float specular_color[3];
+  float hasReflective;
+  float hasRefractive;
+  float indexOfRefraction;
+  float emittance;
+} PtMaterial;
+
+/* Same field order and size (84 B) as `Camera` (sceneStructs.h:50-59). */
+typedef struct PtCamera {
+  int32_t resolution[2];
+  float position[3];
+  float lookAt[3];
+  float view[3];
+  float up[3];
+  float right[3];
+  float fov[2];
+  float pixelLength[2];
+} PtCamera;
+
+/* Same layout (36 B) as BVHNodeGPU (pathtrace.cu:24-32); for inspection/tests. */
+typedef struct PtBVHNode {
+  float bmin[3];
+  float bmax[3];
+  int32_t left, right, geomIndex;
+} PtBVHNode;
+
+typedef struct PtSceneDesc {
+  const PtGeom* geoms;
+  int32_t num_geoms;
+  const PtMaterial* materials;
+  int32_t num_materials;
+  PtCamera camera;     /* after the main.cpp camera fix-up (see pt_scene_load) */
+  int32_t trace_depth; /* RenderState::traceDepth */
+} PtSceneDesc;
+
+typedef struct PtOptions {
+  int32_t device;          /* HIP device ordinal */
+  int32_t pixel_begin;     /* framebuffer tile: global pixel indices             */
+  int32_t pixel_count;     /*   [pixel_begin, pixel_begin+pixel_count); 0 = all  */
+  int32_t iters_per_batch; /* iterations in flight per wavefront batch; 0 = auto */
+  int32_t num_queues;      /* compaction queues; 0 = auto                        */
+  int32_t blocks_per_cu;   /* persistent grid = CUs * blocks_per_cu; 0 = auto    */
+  int32_t time_kernels;    /* 1: bracket every computeIntersections launch with  */
+                           /*    HIP events on the render stream (pt_get_stats)  */
+  int32_t reserved[9];
+} PtOptions;
+
+#define PT_MAX_DEPTH 64
+typedef struct PtStats {
+  int64_t samples;                    /* pixel-samples rendered since pt_init            */
+  int64_t live_rays[PT_MAX_DEPTH];    /* rays traced by computeIntersections per depth   */
+  int64_t intersect_launches;         /* timed computeIntersections launches             */
+  double intersect_ms;                /* sum of their HIP-event durations (time_kernels) */
+  double render_ms;                   /* HIP-event time of all pt_render calls           */
+  int32_t num_cus, grid_blocks, num_queues, iters_per_batch;
+  int64_t device_bytes;               /* device memory held by the renderer              */
+} PtStats;
+
+/* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,
+ * src/scene.cpp:7-188) plus the camera state main.cpp derives before the first
+ * frame (main.cpp:57-71, 110-128).  res_w/res_h > 0 override the RES line,
+ * recomputing fov/pixelLength as scene.cpp:133-140 does. */
+typedef struct PtScene PtScene;
+int pt_scene_load(const char* path, int res_w, int res_h, PtScene** out);
+void pt_scene_free(PtScene* s);
+int pt_scene_desc(const PtScene* s, PtSceneDesc* out); /* pointers valid until pt_scene_free */
+int pt_scene_iterations(const PtScene* s);             /* CAMERA ITERATIONS */
+const char* pt_scene_image_name(const PtScene* s);     /* CAMERA FILE */
+
+/* BVH exactly as pathtraceInit builds it (pathtrace.cu:34-111, 483-489).
+ * Returns node count (2n-1); writes up to `cap` nodes if `out` != NULL. */
+int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap);
+
+/* transform / inverse / inverse-transpose of an OBJECT block's TRANS ROTAT SCALE
+ * (trs[9]), as utilityCore::buildTransformationMatrix + glm::inverse +
+ * glm::inverseTranspose compute them (src/utilities.cpp:64-72, src/scene.cpp:83-86). */
+int pt_build_transform(const float* trs, float* transform, float* inverse, float* invTranspose);
+
+/* ---- renderer (replaces src/pathtrace.h) -------------------------------- */
+int pt_init(const PtSceneDesc* scene, const PtOptions* opt); /* pathtraceInit, pathtrace.cu:462 */
+int pt_free(void);                                           /* pathtraceFree, pathtrace.cu:518; safe
+                                                                before init and twice in a row */
+/* Runs iterations iter_first .. iter_first+iter_count-1 (1-based, as main.cpp:141-145
+ * passes them) and adds them to the accumulation image.  Equivalent to iter_count
+ * calls of pathtrace(pbo=NULL, 0, iter) (pathtrace.cu:529).  Asynchronous on the
+ * renderer's stream; pt_sync / pt_readback wait. */
+int pt_render(int iter_first, int iter_count);
+int pt_sync(void);
+/* Tile SUM image → host (pixel_count*3 floats), pathtrace.cu:648-651. */
+int pt_readback(float* rgb_sum_host);
+/* Tile SUM image → caller-owned device buffer (pixel_count*3 floats) on the
+ * renderer's device; used to feed the RCCL gather without a host hop. */
+int pt_readback_device(void* rgb_sum_dev);
+/* Display conversion of sendImageToPBO (pathtrace.cu:250-268): average, gamma 1/2.2,
+ * clamp → RGBA8 into a host buffer of pixel_count*4 bytes. */
+int pt_preview_rgba8(int iterations, uint8_t* rgba_host);
+int pt_preview_rgba8_device(int iterations, void* rgba_dev); /* same, into a device buffer (the PBO) */
+int pt_get_stats(PtStats* out);
+int pt_reset_stats(void);
+const char* pt_last_error(void);
+
+/* ---- stage-level entry points (same kernels, caller-supplied HOST arrays, SoA:
+ * vec3 arrays are [3][n]).  Used by the parity tests; each uploads, launches the
+ * production kernel, downloads. ----------------------------------------------- */
+/* generateRayFromCamera (pathtrace.cu:270-286) for pixels [pix_begin, pix_begin+n). */
+int pt_stage_generate(int pix_begin, int n, float* origin, float* dir);
+/* computeIntersections (pathtrace.cu:288-333): closest hit per ray. */
+int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, float* normal, int32_t* material,
+                       float* point);
+/* shadeAndExtendRays (pathtrace.cu:336-437) for live paths at `depth`:
+ * in/out origin, dir, color; out alive[n] (1 = path continues).  Dead paths get the
+ * retirement colour (sky factor applied (trace_depth - depth) times on a miss). */
+int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, const float* t, const float* normal,
+                   const int32_t* material, const float* point, float* origin, float* dir, float* color,
+                   int32_t* alive);
+
+/* ---- image output (src/image.cpp:22-45, src/main.cpp:86-107) ------------- */
+/* rgb_sum: W*H*3 floats (raw orientation); writes <path> as 8-bit PNG of
+ * clamp(sum/samples)*255 with the x mirror of saveImage(); no gamma. */
+int pt_save_png(const char* path, const float* rgb_sum, int w, int h, float samples);
+int pt_save_pfm(const char* path, const float* rgb_sum, int w, int h, float samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_AMD_H */

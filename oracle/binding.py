@@ -77,6 +77,10 @@ def lib() -> C.CDLL:
         L.orc_shade.argtypes = [C.c_int, C.c_int, ip, ip, fp, fp, ip, fp, fp, fp, fp, ip]
         L.orc_render.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
                                  C.POINTER(C.c_long)]
+        L.orc_math_eval_f.argtypes = [C.c_int, C.c_int, fp, fp]
+        L.orc_math_eval_d.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_build_xform.argtypes = [fp, fp, fp, fp]
+        L.orc_vecops.argtypes = [fp, fp, fp, fp]
         _lib = L
     return _lib
 
@@ -186,3 +190,32 @@ def render(iter_first: int, iter_count: int, depth: int = 0, variant: int = LITE
     if want_stats:
         return img, dict(live=list(st[0:64]), node_pops=st[64], prim_tests=st[65], max_stack=st[66])
     return img
+
+
+def math_eval_f(fn: int, x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().orc_math_eval_f(fn, x.size, _fp(x), _fp(out))
+    return out
+
+
+def math_eval_d(fn: int, x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    lib().orc_math_eval_d(fn, x.size, x.ctypes.data_as(dp), out.ctypes.data_as(dp))
+    return out
+
+
+def build_xform(trs):
+    t = np.ascontiguousarray(trs, np.float32)
+    m, i, it = (np.zeros(16, np.float32) for _ in range(3))
+    lib().orc_build_xform(_fp(t), _fp(m), _fp(i), _fp(it))
+    return m, i, it
+
+
+def vecops(a, b, m16):
+    out = np.zeros(14, np.float32)
+    lib().orc_vecops(_fp(np.ascontiguousarray(a, np.float32)), _fp(np.ascontiguousarray(b, np.float32)),
+                     _fp(np.ascontiguousarray(m16, np.float32)), _fp(out))
+    return out

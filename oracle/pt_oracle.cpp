@@ -1049,6 +1049,16 @@ void orc_vecops(const float* a3, const float* b3, const float* m16, float* out) 
   v2f(multiplyMV(M, vec4(a, 0.0f)), out + 11);
 }
 
+
+// ---- math-mode probes: fn 0 sinf, 1 cosf, 2 acosf (float in/out), using the CURRENT math mode
+void orc_math_eval_f(int fn, int n, const float* in, float* out) {
+  for (int i = 0; i < n; ++i) out[i] = fn == 0 ? m_sinf(in[i]) : fn == 1 ? m_cosf(in[i]) : m_acosf(in[i]);
+}
+// fn 0 sin, 1 cos (double in/out)
+void orc_math_eval_d(int fn, int n, const double* in, double* out) {
+  for (int i = 0; i < n; ++i) out[i] = fn == 0 ? m_sin(in[i]) : m_cos(in[i]);
+}
+
 // ---- known-answer helpers -------------------------------------------------
 uint32_t orc_utilhash(uint32_t a) { return utilhash(a); }
 int32_t orc_seed(int iter, int index, int depth) { return (int32_t)seedHash(iter, index, depth); }
