@@ -1,0 +1,52 @@
+"""Multi-GPU partition of the framebuffer.
+
+Every (iteration, pixel) sample is independent and its RNG stream is keyed by the GLOBAL
+pixel index (reference: makeSeededRandomEngine(iter, idx, depth), src/pathtrace.cu:203-207,368),
+so the frame is cut into one contiguous block of rows per rank; each rank renders its tile for
+all iterations with no communication, and the float tiles are collected once, at image
+write-out, with a single gather (RCCL over xGMI when the backend is "nccl").  The assembled
+image is bit-identical to the single-GPU image: nothing is summed across GPUs.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+
+def tile_rows(height: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rows [r0, r1) owned by `rank`: the first (height % world) ranks get one extra row."""
+    base, extra = divmod(height, world)
+    r0 = rank * base + min(rank, extra)
+    return r0, r0 + base + (1 if rank < extra else 0)
+
+
+def tile_for_rank(width: int, height: int, rank: int, world: int) -> Tuple[int, int]:
+    """(pixel_begin, pixel_count) of the rank's tile in global pixel indices (idx = x + y*W)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    if world > height:
+        raise ValueError(f"more ranks ({world}) than image rows ({height})")
+    r0, r1 = tile_rows(height, rank, world)
+    return r0 * width, (r1 - r0) * width
+
+
+def gather_tiles(tile, width: int, height: int, rank: int, world: int, dst: int = 0):
+    """Collect per-rank tiles ([count, 3] float32 tensors, on the GPU for nccl) on rank `dst`
+    and return the assembled [H*W, 3] image there (None elsewhere).  One collective."""
+    if world == 1:
+        return tile
+    import torch
+    import torch.distributed as dist
+
+    counts = [tile_for_rank(width, height, r, world)[1] for r in range(world)]
+    assert tile.shape[0] == counts[rank], (tile.shape, counts[rank])
+    pad = max(counts)
+    send = tile
+    if tile.shape[0] != pad:  # gather needs equal-sized buffers
+        send = torch.zeros((pad, 3), dtype=tile.dtype, device=tile.device)
+        send[: tile.shape[0]] = tile
+    if rank == dst:
+        bufs: List = [torch.empty((pad, 3), dtype=tile.dtype, device=tile.device) for _ in range(world)]
+        dist.gather(send, gather_list=bufs, dst=dst)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    dist.gather(send, gather_list=None, dst=dst)
+    return None

@@ -1,0 +1,73 @@
+"""The N>1 path on CPU: tile partition + single gather over torch.distributed (gloo, world 2 and 3).
+Each rank "renders" its tile with the oracle (stand-in for its GPU; tests may use the oracle) using
+GLOBAL pixel indices; the gathered image must be bit-identical to the single-process image."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cosc_4397_pathtracing_raytracing_project_amd import parallel
+
+
+def test_tile_partition_covers_frame_exactly():
+    for (w, h) in ((1920, 1080), (800, 800), (7, 5)):
+        for world in (1, 2, 3, 4, 5):
+            if world > h:
+                continue
+            spans = [parallel.tile_for_rank(w, h, r, world) for r in range(world)]
+            assert spans[0][0] == 0
+            for (b0, c0), (b1, _) in zip(spans, spans[1:]):
+                assert b0 + c0 == b1 and c0 % w == 0
+            assert spans[-1][0] + spans[-1][1] == w * h
+            rows = [c // w for _, c in spans]
+            assert max(rows) - min(rows) <= 1
+    assert parallel.tile_for_rank(1920, 1080, 3, 8) == (3 * 135 * 1920, 135 * 1920)
+    with pytest.raises(ValueError):
+        parallel.tile_for_rank(4, 2, 0, 3)
+    with pytest.raises(ValueError):
+        parallel.tile_for_rank(4, 4, 4, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, scene_path, res, spp, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import binding as ob
+    ob.set_math_mode(ob.PORTABLE)
+    ob.load_scene(scene_path, res=res)
+    begin, count = parallel.tile_for_rank(res[0], res[1], rank, world)
+    tile = torch.from_numpy(ob.render(1, spp, depth=8, variant=ob.RETIRE, pix_begin=begin, pix_count=count))
+    full = parallel.gather_tiles(tile, res[0], res[1], rank, world)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_reassembles_single_process_image(scene_dir, tmp_path, world):
+    res, spp = (48, 31), 3  # 31 rows: uneven tiles, exercises the padded gather
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker, args=(world, _free_port(), scene_dir["cornell"], res, spp, out), nprocs=world, join=True)
+    from oracle import binding as ob
+    ob.set_math_mode(ob.PORTABLE)
+    ob.load_scene(scene_dir["cornell"], res=res)
+    ref = ob.render(1, spp, depth=8, variant=ob.RETIRE)
+    ob.set_math_mode(ob.LIBM)
+    got = np.load(out)
+    assert got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
