@@ -55,7 +55,8 @@ struct Ctx {
   int depth = 0;
   // tile / batch geometry
   int N = 0, pixel_begin = 0, K = 1;
-  int num_cus = 0, grid = 0;
+  int num_cus = 0, grid = 0;  // grid: widest persistent grid (stats / test stages)
+  int grid_gen = 0, grid_isect = 0, grid_shade = 0;
   ptd::Queues qs{};
   int64_t stride = 0;  // plane stride = Q*cap
   // device memory
@@ -172,6 +173,13 @@ int alloc_hitbuf(ptd::HitBuf* h, int64_t stride) {
   return 0;
 }
 
+// Queue descriptor for a launch of `grid` workgroups (W = waves of THAT launch; Q, cap shared).
+ptd::Queues queues_for(int grid) {
+  ptd::Queues q = g.qs;
+  q.W = grid * ptk::kWavesPerBlock;
+  return q;
+}
+
 int run_batch(int iter_first, int kb) {
   ptk::BatchInfo b{};
   b.iter_first = iter_first;
@@ -181,7 +189,7 @@ int run_batch(int iter_first, int kb) {
   b.trace_depth = g.depth;
   const size_t cnt_ints = (size_t)(g.depth + 1) * g.qs.Q * g.qs.cnt_stride;
   HIP_OK(hipMemsetAsync(g.d_cnt, 0, cnt_ints * sizeof(int32_t), g.stream));
-  ptk::launch_generate(g.stream, g.grid, g.dcam, b, g.qs, g.buf[0], g.d_cnt);
+  ptk::launch_generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g.grid_gen), g.buf[0], g.d_cnt);
   const ptk::SceneTables sc = tables();
   const size_t per_depth = (size_t)g.qs.Q * g.qs.cnt_stride;
   for (int d = 0; d < g.depth; ++d) {
@@ -192,12 +200,13 @@ int run_batch(int iter_first, int kb) {
       if (get_events(&ev)) return -1;
       HIP_OK(hipEventRecord(ev.a, g.stream));
     }
-    ptk::launch_intersect(g.stream, g.grid, sc, g.qs, cin, g.buf[d & 1], g.hits);
+    ptk::launch_intersect(g.stream, g.grid_isect, sc, queues_for(g.grid_isect), cin, g.buf[d & 1], g.hits);
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
       g.pending_isect.push_back(ev);
     }
-    ptk::launch_shade(g.stream, g.grid, sc, b, d, g.qs, cin, cout, g.buf[d & 1], g.hits, g.buf[(d + 1) & 1], g.d_final);
+    ptk::launch_shade(g.stream, g.grid_shade, sc, b, d, queues_for(g.grid_shade), cin, cout, g.buf[d & 1], g.hits,
+                      g.buf[(d + 1) & 1], g.d_final);
   }
   ptk::launch_count_stats(g.stream, g.qs, g.d_cnt, g.depth, g.d_stats);
   ptk::launch_gather(g.stream, b, g.d_final, g.d_image);
@@ -352,15 +361,15 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   while ((int64_t)K * g.N > (1ll << 30) && K > 1) --K;
   g.K = K;
 
-  const int bpc = opt.blocks_per_cu > 0 ? opt.blocks_per_cu : 8;
+  // Compaction queues: every launch needs (waves % Q) == 0, so Q divides 4 * CUs.
   int Q = opt.num_queues > 0 ? opt.num_queues : 256;
-  const int grid = std::max(1, g.num_cus * bpc);
-  const int Wv = grid * ptk::kWavesPerBlock;
-  if (Q > Wv) Q = Wv;
-  while (Wv % Q) --Q;  // every queue is served by the same number of waves
+  const int cu_waves = g.num_cus * ptk::kWavesPerBlock;
+  if (Q > cu_waves) Q = cu_waves;
+  while (cu_waves % Q) --Q;
+  const int grid = g.num_cus * 8;
   g.grid = grid;
   g.qs.Q = Q;
-  g.qs.W = Wv;
+  g.qs.W = grid * ptk::kWavesPerBlock;
   g.qs.cnt_stride = 16;
   const int64_t total = (int64_t)K * g.N;
   const int64_t chunks = (total + 63) / 64;
@@ -398,6 +407,13 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
 
+  {
+    const ptk::SceneTables t = tables();
+    const int cap_bpc = opt.blocks_per_cu > 0 ? std::min(opt.blocks_per_cu, 8) : 8;
+    g.grid_gen = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kGenerate, t));
+    g.grid_isect = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kIntersect, t));
+    g.grid_shade = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kShade, t));
+  }
   // path state
   if (alloc_pathbuf(&g.buf[0], g.stride) || alloc_pathbuf(&g.buf[1], g.stride) || alloc_hitbuf(&g.hits, g.stride)) return -1;
   if (dalloc(&g.d_final, 3 * (size_t)total) || dalloc(&g.d_image, 3 * (size_t)g.N)) return -1;
@@ -485,7 +501,7 @@ int pt_get_stats(PtStats* out) {
   out->intersect_ms = g.isect_ms;
   out->render_ms = g.render_ms;
   out->num_cus = g.num_cus;
-  out->grid_blocks = g.grid;
+  out->grid_blocks = g.grid_isect;
   out->num_queues = g.qs.Q;
   out->iters_per_batch = g.K;
   out->device_bytes = g.device_bytes;

@@ -46,6 +46,12 @@ void launch_count_stats(hipStream_t s, const ptd::Queues& qs, const int32_t* cnt
 // sendImageToPBO (pathtrace.cu:250-268)
 void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba);
 
+// Resident workgroups per CU for each persistent kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor),
+// so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
+// a workgroup that has to wait for a free slot would run its whole share after everybody else.
+enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2 };
+int resident_blocks_per_cu(KernelId id, const SceneTables& sc);
+
 // Stage helper for tests: one shading step on n explicit paths (single queue, no compaction):
 // writes alive flags and in-place o/d/color.
 void launch_shade_stage(hipStream_t s, const SceneTables& sc, int trace_depth, int depth, int n, const int32_t* iter,

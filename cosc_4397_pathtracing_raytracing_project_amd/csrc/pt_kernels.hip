@@ -517,6 +517,26 @@ inline int round16(int x) { return (x + 15) & ~15; }
 }  // namespace
 
 // ───────────────────────────── launch wrappers ─────────────────────────────
+int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
+  int n = 0;
+  hipError_t e = hipSuccess;
+  const int tbl = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
+  switch (id) {
+    case kGenerate:
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_generate, kBlock, 0);
+      break;
+    case kIntersect:
+      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true>, kBlock, round16(tbl));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false>, kBlock, 0);
+      break;
+    case kShade:
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)));
+      break;
+  }
+  if (e != hipSuccess || n < 1) n = 1;
+  return n > 8 ? 8 : n;
+}
+
 void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
                      ptd::PathBuf out, int32_t* cnt0) {
   hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, cam, b, qs, out, cnt0);
