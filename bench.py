@@ -74,6 +74,7 @@ def main() -> None:
     ap.add_argument("--iters-per-batch", type=int, default=0)
     ap.add_argument("--queues", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--legacy-traversal", action="store_true", help="A/B: per-lane BVH walk kernel")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket intersect launches with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and psnr (N=1 extras)")
     ap.add_argument("--save", type=str, default="", help="write the final image as PREFIX.png/.pfm")
@@ -108,7 +109,8 @@ def main() -> None:
     def make_renderer(time_kernels: bool):
         return capi.Renderer(scene, device=local_rank, pixel_begin=begin, pixel_count=count,
                              iters_per_batch=args.iters_per_batch, num_queues=args.queues,
-                             blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels)
+                             blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels,
+                             legacy_traversal=args.legacy_traversal)
 
     def barrier():
         if world > 1:
@@ -176,7 +178,8 @@ def main() -> None:
                    "iters_per_batch": int(st.iters_per_batch), "queues": int(st.num_queues),
                    "grid_blocks": int(st.grid_blocks), "cus": int(st.num_cus),
                    "device_mem_mb": round(st.device_bytes / 2 ** 20, 1),
-                   "kernel_events": not args.no_kernel_events},
+                   "kernel_events": not args.no_kernel_events,
+                   "traversal": "legacy per-lane" if args.legacy_traversal else "wave-cooperative"},
         "roofline": roofline,
     }
 

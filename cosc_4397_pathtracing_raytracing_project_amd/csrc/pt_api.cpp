@@ -65,7 +65,9 @@ struct Ctx {
   ptd::Node* d_nodes = nullptr;
   ptd::Geom* d_geoms = nullptr;
   ptd::Mat* d_mats = nullptr;
-  int num_nodes = 0;
+  ptd::TopEntry* d_top = nullptr;
+  int num_nodes = 0, num_top = 0;
+  bool legacy = false;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
   float* d_final = nullptr;
@@ -125,19 +127,47 @@ int resolve_events() {  // requires the stream to be idle
 // Re-emit the reference-order BVH (node, left, right links) in visiting order with
 // skip links (see ptd::Node).  Visiting order of the reference's stack walk is:
 // node, then its RIGHT subtree, then its LEFT subtree (pathtrace.cu:321-322).
-void thread_bvh(const std::vector<PtBVHNode>& in, int idx, std::vector<ptd::Node>& out) {
+void thread_bvh(const std::vector<PtBVHNode>& in, int idx, std::vector<ptd::Node>& out, std::vector<int>& where) {
   const PtBVHNode& n = in[idx];
   const size_t self = out.size();
+  where[idx] = (int)self;
   ptd::Node t{};
   std::memcpy(t.bmin, n.bmin, 12);
   std::memcpy(t.bmax, n.bmax, 12);
   t.geom = n.left < 0 ? n.geomIndex : -1;
   out.push_back(t);
   if (n.left >= 0) {
-    thread_bvh(in, n.right, out);
-    thread_bvh(in, n.left, out);
+    thread_bvh(in, n.right, out, where);
+    thread_bvh(in, n.left, out, where);
   }
   out[self].skip = (int32_t)out.size();
+}
+
+// Flatten the top of the tree into at most ptk::kMaxTop entries (see ptd::TopEntry): start from
+// the root and keep splitting the inner entry that covers the most nodes.
+void build_top(const std::vector<PtBVHNode>& ref, const std::vector<ptd::Node>& thr, const std::vector<int>& where,
+               const std::vector<PtGeom>& geoms, std::vector<ptd::TopEntry>& top) {
+  std::vector<int> cut{0};
+  auto span = [&](int ref_idx) { return thr[where[ref_idx]].skip - where[ref_idx]; };
+  while ((int)cut.size() < ptk::kMaxTop) {
+    int best = -1;
+    for (size_t i = 0; i < cut.size(); ++i)
+      if (ref[cut[i]].left >= 0 && (best < 0 || span(cut[i]) > span(cut[best]))) best = (int)i;
+    if (best < 0) break;
+    const PtBVHNode n = ref[cut[best]];
+    cut[best] = n.right;
+    cut.push_back(n.left);
+  }
+  top.clear();
+  for (int ref_idx : cut) {
+    const PtBVHNode& n = ref[ref_idx];
+    ptd::TopEntry e{};
+    std::memcpy(e.bmin, n.bmin, 12);
+    std::memcpy(e.bmax, n.bmax, 12);
+    e.idx = where[ref_idx];
+    e.link = n.left < 0 ? -1 - geoms[n.geomIndex].type : thr[where[ref_idx]].skip;
+    top.push_back(e);
+  }
 }
 
 void pack_rows(const float m16[16], float out12[12]) {
@@ -153,6 +183,8 @@ ptk::SceneTables tables() {
   t.num_geoms = (int)g.geoms.size();
   t.mats = g.d_mats;
   t.num_mats = (int)g.mats.size();
+  t.top = g.d_top;
+  t.num_top = g.num_top;
   return t;
 }
 
@@ -200,7 +232,7 @@ int run_batch(int iter_first, int kb) {
       if (get_events(&ev)) return -1;
       HIP_OK(hipEventRecord(ev.a, g.stream));
     }
-    ptk::launch_intersect(g.stream, g.grid_isect, sc, queues_for(g.grid_isect), cin, g.buf[d & 1], g.hits);
+    ptk::launch_intersect(g.stream, g.grid_isect, sc, queues_for(g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy);
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
       g.pending_isect.push_back(ev);
@@ -381,8 +413,13 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   pt::buildBVH(g.geoms.data(), (int)g.geoms.size(), ref_nodes);
   std::vector<ptd::Node> nodes;
   nodes.reserve(ref_nodes.size());
-  thread_bvh(ref_nodes, 0, nodes);
+  std::vector<int> where(ref_nodes.size(), -1);
+  thread_bvh(ref_nodes, 0, nodes, where);
   g.num_nodes = (int)nodes.size();
+  std::vector<ptd::TopEntry> top;
+  build_top(ref_nodes, nodes, where, g.geoms, top);
+  g.num_top = (int)top.size();
+  g.legacy = opt.legacy_traversal != 0;
   std::vector<ptd::Geom> dg(g.geoms.size());
   for (size_t i = 0; i < g.geoms.size(); ++i) {
     std::memset(&dg[i], 0, sizeof(ptd::Geom));
@@ -402,7 +439,10 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
     dm[i].emittance = g.mats[i].emittance;
   }
   if (dm.size() * sizeof(ptd::Mat) > 60 * 1024) return fail("pt_init: %zu materials exceed the LDS table", dm.size());
-  if (dalloc(&g.d_nodes, nodes.size()) || dalloc(&g.d_geoms, dg.size()) || dalloc(&g.d_mats, dm.size())) return -1;
+  if (dalloc(&g.d_nodes, nodes.size()) || dalloc(&g.d_geoms, dg.size()) || dalloc(&g.d_mats, dm.size()) ||
+      dalloc(&g.d_top, top.size()))
+    return -1;
+  HIP_OK(hipMemcpy(g.d_top, top.data(), top.size() * sizeof(ptd::TopEntry), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
@@ -411,7 +451,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
     const ptk::SceneTables t = tables();
     const int cap_bpc = opt.blocks_per_cu > 0 ? std::min(opt.blocks_per_cu, 8) : 8;
     g.grid_gen = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kGenerate, t));
-    g.grid_isect = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kIntersect, t));
+    g.grid_isect = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
     g.grid_shade = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kShade, t));
   }
   // path state
@@ -570,7 +610,7 @@ int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, f
     HIP_OK(hipMemcpy(pb.d + c * cap, dir + (size_t)c * n, (size_t)n * 4, hipMemcpyHostToDevice));
   }
   HIP_OK(hipMemcpy(cnt, &n, 4, hipMemcpyHostToDevice));
-  ptk::launch_intersect(g.stream, g.grid, tables(), qs, cnt, pb, hb);
+  ptk::launch_intersect(g.stream, g.grid, tables(), qs, cnt, pb, hb, g.legacy);
   HIP_OK(hipStreamSynchronize(g.stream));
   HIP_OK(hipMemcpy(t, hb.t, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(material, hb.mat, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -24,6 +24,20 @@ struct Node {
 };
 static_assert(sizeof(Node) == 32, "Node must be 32 B");
 
+// Entry of the flattened BVH top ("top list").  A leaf is a candidate for a ray exactly when
+// the ray passes the leaf's own AABB test: ancestors' boxes are unions of their children and
+// the slab arithmetic is monotone, so an ancestor can never reject a ray its descendant
+// accepts.  Inner nodes are therefore pure acceleration, and the top of the tree is replaced
+// by a short list every ray tests with wave-uniform (scalar-loaded) box data; only subtrees
+// below the cut are walked per lane.  For cornell.txt the cut is the 7 leaves themselves.
+struct TopEntry {
+  float bmin[3];
+  float bmax[3];
+  int32_t idx;   // threaded index of the leaf / subtree root (leaf: also the first-found order key)
+  int32_t link;  // >= 0: subtree, one past its last threaded node;  < 0: leaf of type (-1 - link)
+};
+static_assert(sizeof(TopEntry) == 32, "TopEntry must be 32 B");
+
 // Geometry record, 160 B.  Only rows 0..2 of each matrix are ever used
 // (multiplyMV returns vec3, src/intersections.h:34-36), stored m[c*3+r] == glm m[c][r].
 struct Geom {

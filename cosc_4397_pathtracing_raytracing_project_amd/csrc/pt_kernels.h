@@ -9,6 +9,9 @@ namespace ptk {
 constexpr int kBlock = 256;        // 4 wave64 per workgroup
 constexpr int kWavesPerBlock = 4;
 constexpr int kLdsTableBytes = 64 * 1024;  // scene tables are staged in LDS up to this size
+constexpr int kMaxTop = 24;                // entries in the flattened BVH top
+constexpr int kCandCap = 192;              // per-wave candidate list entries (LDS)
+constexpr int kWaveLds = 64 * 8 + 7 * 64 * 4 + kCandCap * 4;  // best keys + winner records + list = 3072 B
 
 struct SceneTables {
   const ptd::Node* nodes;  // threaded DFS order
@@ -17,6 +20,8 @@ struct SceneTables {
   int32_t num_geoms;
   const ptd::Mat* mats;
   int32_t num_mats;
+  const ptd::TopEntry* top;  // flattened BVH top (see ptd::TopEntry)
+  int32_t num_top;
 };
 
 struct BatchInfo {
@@ -33,7 +38,7 @@ void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const Batc
                      ptd::PathBuf out, int32_t* cnt0);
 // computeIntersections over the live paths of every queue.
 void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
-                      ptd::PathBuf paths, ptd::HitBuf hits);
+                      ptd::PathBuf paths, ptd::HitBuf hits, bool legacy = false);
 // shadeAndExtendRays + compaction + retirement.
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
@@ -49,7 +54,7 @@ void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb
 // Resident workgroups per CU for each persistent kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor),
 // so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
 // a workgroup that has to wait for a free slot would run its whole share after everybody else.
-enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2 };
+enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3 };
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc);
 
 // Stage helper for tests: one shading step on n explicit paths (single queue, no compaction):

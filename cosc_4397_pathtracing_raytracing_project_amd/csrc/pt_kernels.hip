@@ -141,17 +141,19 @@ struct HitRec {
   int geom;
 };
 
-// Primitive test shared by cube and sphere: the object-space transform of the ray and
-// the world-space reconstruction of point/normal/distance are common code; only the
-// middle (slab vs quadratic) diverges.  Returns t (-1 = no hit).
+// Primitive tests.  The object-space transform of the ray and the world-space reconstruction of
+// point / normal / distance are common to both types; only the middle (slab vs quadratic) differs.
+// TYPE: 1 cube (boxIntersectionTest, intersections.h:48-90), 0 sphere (sphereIntersectionTest,
+// intersections.h:102-144), -1 decided per lane from G->type.  Returns t (-1 = no hit).
+template <int TYPE>
 PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& point, f3& normal) {
   const f3 qo = mulMV(G->inv, ro_w, 1.0f);
   const f3 qd = normalize(mulMV(G->inv, rd_w, 0.0f));
+  const bool is_box = TYPE < 0 ? (G->type == 1) : (TYPE == 1);
   float t;
-  f3 nobj;
+  f3 nobj = mk(0.f, 0.f, 0.f);
   bool flip = false;
-  if (G->type == 1) {
-    // boxIntersectionTest, intersections.h:48-90
+  if (is_box) {
     float tmin = -1e38f, tmax = 1e38f;
     f3 tmin_n = mk(0.f, 0.f, 0.f), tmax_n = mk(0.f, 0.f, 0.f);
     const float qdv[3] = {qd.x, qd.y, qd.z};
@@ -181,7 +183,7 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
     t = tmin;
     nobj = tmin_n;
   } else {
-    // sphereIntersectionTest, intersections.h:102-144 (radius .5 → powf(.5,2) = .25)
+    // radius .5 → powf(.5, 2) = .25
     const float vDotDirection = dot(qo, qd);
     const float radicand = vDotDirection * vDotDirection - (dot(qo, qo) - 0.25f);
     if (radicand < 0.f) return -1.0f;
@@ -196,47 +198,58 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
       t = t1 < t2 ? t2 : t1;  // max(t1, t2)
       flip = true;            // !outside → normal negated
     }
-    nobj = mk(0.f, 0.f, 0.f);
   }
   // getPointOnRay (intersections.h:27-29): origin + (t - .0001f) * normalize(direction)
   const f3 objp = add(qo, scl(normalize(qd), t - .0001f));
-  if (G->type != 1) nobj = objp;
+  if (!is_box) nobj = objp;
   point = mulMV(G->xf, objp, 1.0f);
   normal = normalize(mulMV(G->invT, nobj, 0.0f));
   if (flip) normal = neg(normal);
   return length(sub(ro_w, point));
 }
 
-// Closest hit for one ray; `nodes`/`geoms` may point to LDS or global memory.
+// intersectAABB (pathtrace.cu:113-128) with the reciprocal direction hoisted (the reference
+// recomputes 1/dir per node, same value) and the swap expressed as a select on its sign.
+// The reference returns false at the first axis with tmax <= tmin; tmin only grows and tmax only
+// shrinks, so one test after the third axis is equivalent.
+struct RayInv {
+  float ix, iy, iz;
+  bool sx, sy, sz;
+};
+PT_DEV RayInv ray_inv(f3 d) {
+  RayInv r;
+  r.ix = 1.0f / d.x, r.iy = 1.0f / d.y, r.iz = 1.0f / d.z;
+  r.sx = r.ix < 0.0f, r.sy = r.iy < 0.0f, r.sz = r.iz < 0.0f;
+  return r;
+}
+PT_DEV bool slab(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+  const float t0x = ((ri.sx ? hix : lox) - o.x) * ri.ix;
+  const float t1x = ((ri.sx ? lox : hix) - o.x) * ri.ix;
+  const float t0y = ((ri.sy ? hiy : loy) - o.y) * ri.iy;
+  const float t1y = ((ri.sy ? loy : hiy) - o.y) * ri.iy;
+  const float t0z = ((ri.sz ? hiz : loz) - o.z) * ri.iz;
+  const float t1z = ((ri.sz ? loz : hiz) - o.z) * ri.iz;
+  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
+  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
+  return !(tmax <= tmin);
+}
+
+// Legacy traversal (kept for A/B measurements, PtOptions flag): one lane walks the threaded
+// tree and runs each primitive test as soon as the wave reaches it.
 PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const ptd::Geom* __restrict__ geoms, f3 o, f3 d) {
   HitRec h;
   h.t = FLT_MAX;
   h.geom = -1;
   h.n = mk(0.f, 0.f, 0.f);
   h.p = mk(0.f, 0.f, 0.f);
-  // intersectAABB recomputes 1/dir per node (pathtrace.cu:116); same value every time.
-  const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-  const bool sx = ix < 0.0f, sy = iy < 0.0f, sz = iz < 0.0f;
+  const RayInv ri = ray_inv(d);
   int i = 0;
   while (true) {
     int g = -1;
-    // forward scan until this lane reaches a leaf whose box it enters (or the end);
-    // the primitive test is postponed so that lanes of the wave run it together.
     while (i < num_nodes) {
       const float4 A = reinterpret_cast<const float4*>(nodes)[2 * i];      // bmin.xyz, bmax.x
       const float4 B = reinterpret_cast<const float4*>(nodes)[2 * i + 1];  // bmax.yz, skip, geom
-      // t0 = (min - o) * invD, t1 = (max - o) * invD, swapped when invD < 0
-      const float t0x = ((sx ? A.w : A.x) - o.x) * ix;
-      const float t1x = ((sx ? A.x : A.w) - o.x) * ix;
-      const float t0y = ((sy ? B.x : A.y) - o.y) * iy;
-      const float t1y = ((sy ? A.y : B.x) - o.y) * iy;
-      const float t0z = ((sz ? B.y : A.z) - o.z) * iz;
-      const float t1z = ((sz ? A.z : B.y) - o.z) * iz;
-      const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
-      const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
-      // The reference returns false at the first axis with tmax <= tmin; tmin only grows
-      // and tmax only shrinks, so that is equivalent to one test after the third axis.
-      if (tmax <= tmin) {
+      if (!slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y)) {
         i = __float_as_int(B.z);
         continue;
       }
@@ -249,7 +262,7 @@ PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const pt
     }
     if (g < 0) break;
     f3 pt, nrm;
-    const float t = geom_test(geoms + g, o, d, pt, nrm);
+    const float t = geom_test<-1>(geoms + g, o, d, pt, nrm);
     if (t > 0.f && t < h.t) {  // strict <: first found wins ties (pathtrace.cu:314)
       h.t = t;
       h.geom = g;
@@ -261,8 +274,9 @@ PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const pt
 }
 
 template <bool TABLES_IN_LDS>
-__global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queues qs, const int32_t* __restrict__ cnt_in,
-                                                      ptd::PathBuf paths, ptd::HitBuf hits) {
+__global__ __launch_bounds__(kBlock) void k_intersect_legacy(SceneTables sc, ptd::Queues qs,
+                                                             const int32_t* __restrict__ cnt_in, ptd::PathBuf paths,
+                                                             ptd::HitBuf hits) {
   extern __shared__ float4 lds_raw[];
   const ptd::Node* nodes = sc.nodes;
   const ptd::Geom* geoms = sc.geoms;
@@ -294,6 +308,202 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
       hits.mat[at] = hit ? geoms[h.geom].material : 0;
       hits.p[at] = h.p.x, hits.p[HS + at] = h.p.y, hits.p[2 * HS + at] = h.p.z;
     }
+  }
+}
+
+// ── computeIntersections, wave-cooperative form ──────────────────────────────────────────
+// Per group of 64 rays a wave runs
+//   phase 1  candidate search: every lane tests its ray against the flattened BVH top (box data
+//            wave-uniform → scalar loads) and walks entered subtrees with the stackless scan;
+//            each (ray, leaf) whose AABB test passes is appended to a per-wave LDS list with a
+//            ballot + mbcnt prefix — cubes from the front, spheres from the back;
+//   phase 2  primitive tests over the list in dense 64-entry chunks, so all lanes run the same
+//            (type-specialised) code on useful work; the ray is fetched from its owner lane with
+//            ds_bpermute; the closest hit per ray is kept with an LDS 64-bit atomic min on
+//            (t bits << 32 | leaf index).  The reference takes a hit iff t > 0 && t < t_min in its
+//            DFS visiting order (pathtrace.cu:314), i.e. the smallest t and, among equal t, the
+//            leaf visited first; leaves are numbered in that order, so the key's minimum is
+//            exactly the reference's choice no matter in which order candidates are evaluated.
+// The reference has no t_min culling, so the candidate set does not depend on hit results and
+// the two phases are independent.
+struct WaveLds {
+  unsigned long long* best;  // [64]
+  float* rec;                // [7][64]: normal xyz, point xyz (+1 spare row not allocated)
+  uint32_t* list;            // [kCandCap]: (leaf index << 6) | owner lane
+};
+constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;  // t_min = FLT_MAX
+
+PT_DEV float bperm(int src_lane, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
+// Runs the pending candidates; called at wave-uniform control flow with all 64 lanes active.
+PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
+                             const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+  const int total = nb + ns;
+  for (int base = 0; base < total; base += 64) {
+    const int e = base + lane;
+    const bool valid = e < total;
+    const bool is_box = e < nb;
+    const uint32_t entry = valid ? w.list[is_box ? e : kCandCap - total + e] : (uint32_t)lane;
+    const int src = (int)(entry & 63u);
+    const uint32_t leaf = entry >> 6;
+    const f3 ro = mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
+    const f3 rd = mk(bperm(src, d.x), bperm(src, d.y), bperm(src, d.z));
+    const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
+    f3 pt, nrm;
+    float t;
+    if (base + 64 <= nb) t = geom_test<1>(G, ro, rd, pt, nrm);       // chunk of cubes only
+    else if (base >= nb) t = geom_test<0>(G, ro, rd, pt, nrm);      // chunk of spheres only
+    else t = is_box ? geom_test<1>(G, ro, rd, pt, nrm) : geom_test<0>(G, ro, rd, pt, nrm);
+    const uint32_t tb = __float_as_uint(t);
+    if (valid && t > 0.f && tb < 0x7f7fffffu) {
+      const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
+      atomicMin(&w.best[src], key);
+      if (w.best[src] == key) {  // this candidate is the ray's best so far: publish its record
+        w.rec[0 * 64 + src] = nrm.x, w.rec[1 * 64 + src] = nrm.y, w.rec[2 * 64 + src] = nrm.z;
+        w.rec[3 * 64 + src] = pt.x, w.rec[4 * 64 + src] = pt.y, w.rec[5 * 64 + src] = pt.z;
+      }
+    }
+  }
+}
+
+template <bool TABLES_IN_LDS>
+__global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queues qs, const int32_t* __restrict__ cnt_in,
+                                                      ptd::PathBuf paths, ptd::HitBuf hits) {
+  extern __shared__ float4 lds_raw[];
+  char* lds = reinterpret_cast<char*>(lds_raw);
+  // LDS map: [top list][nodes][geoms] (tables, if they fit) then one WaveLds block per wave
+  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  stage16(lds, sc.top, nb_top);
+  const float4* top = reinterpret_cast<const float4*>(lds);
+  const ptd::Node* nodes = sc.nodes;
+  const ptd::Geom* geoms = sc.geoms;
+  int tbl = nb_top;
+  if (TABLES_IN_LDS) {
+    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
+    stage16(lds + nb_top, sc.nodes, nb_nodes);
+    stage16(lds + nb_top + nb_nodes, sc.geoms, nb_geoms);
+    nodes = reinterpret_cast<const ptd::Node*>(lds + nb_top);
+    geoms = reinterpret_cast<const ptd::Geom*>(lds + nb_top + nb_nodes);
+    tbl += nb_nodes + nb_geoms;
+  }
+  __syncthreads();
+  const int wib = threadIdx.x >> 6;
+  WaveLds w;
+  {
+    char* base = lds + tbl + wib * kWaveLds;
+    w.best = reinterpret_cast<unsigned long long*>(base);
+    w.rec = reinterpret_cast<float*>(base + 64 * 8);
+    w.list = reinterpret_cast<uint32_t*>(base + 64 * 8 + 7 * 64 * 4);
+  }
+  const int ntop = sc.num_top;
+
+  const int wave = blockIdx.x * kWavesPerBlock + wib;
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
+  const int64_t S = paths.stride, HS = hits.stride;
+  const int64_t qbase = (int64_t)q * qs.cap;
+  // Memory operations are kept branch-free so that the compiler can count them (s_waitcnt vmcnt(N)
+  // is in-order): every lane of a group loads and stores, lanes past the queue's fill level touch the
+  // unused tail of the queue's own region (cap is a multiple of 64, so roundup64(n_q) <= cap) and
+  // their results are ignored.  The NEXT group's rays are loaded before the current group is traced
+  // (software pipeline): their HBM latency overlaps ~1k instructions of work.
+  const int last = qs.cap - 64 + lane;  // clamp for the prefetch beyond the last group
+  f3 no, nd;
+  {
+    const int64_t a0 = qbase + min(r * 64 + lane, last);
+    no = mk(paths.o[a0], paths.o[S + a0], paths.o[2 * S + a0]);
+    nd = mk(paths.d[a0], paths.d[S + a0], paths.d[2 * S + a0]);
+  }
+  for (int j = r; j * 64 < n_q; j += wq) {
+    const int i = j * 64 + lane;
+    const bool valid = i < n_q;
+    const int64_t at = qbase + i;
+    const f3 o = no, d = nd;
+    {
+      const int64_t an = qbase + min((j + wq) * 64 + lane, last);
+      no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
+      nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
+    }
+    const RayInv ri = ray_inv(d);
+    w.best[lane] = kNoHit;
+    int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
+
+    // top list: wave-uniform LDS reads (broadcast), entry e+1 fetched while entry e is tested
+    float4 A = top[0], B = top[1];
+    for (int e = 0; e < ntop; ++e) {
+      const float4 TA = A, TB = B;  // bmin.xyz, bmax.x | bmax.yz, idx, link
+      if (e + 1 < ntop) A = top[2 * e + 2], B = top[2 * e + 3];
+      const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
+      const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
+      const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
+      if (t_link < 0) {  // leaf entry: type is wave-uniform
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+          if (nb + ns + 64 > kCandCap) {
+            flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+            nb = ns = 0;
+          }
+          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+          const int cnt = __popcll(m);
+          const uint32_t entry = ((uint32_t)t_idx << 6) | (uint32_t)lane;
+          if (t_link == -2) {  // cube
+            if (pass) w.list[nb + rank] = entry;
+            nb += cnt;
+          } else {
+            if (pass) w.list[kCandCap - ns - cnt + rank] = entry;
+            ns += cnt;
+          }
+        }
+      } else {  // subtree [idx, link): stackless scan, lanes that did not enter idle
+        int cur = pass ? t_idx : t_link;
+        while (__ballot(cur < t_link)) {
+          const bool act = cur < t_link;
+          const int at_n = act ? cur : t_idx;
+          const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
+          const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
+          const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
+          const int g = __float_as_int(NB.w);
+          const bool cand = in && g >= 0;
+          const bool cbox = cand && geoms[g].type == 1;
+          const bool csph = cand && !cbox;
+          const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
+          if (mb | msp) {
+            if (nb + ns + 128 > kCandCap) {
+              flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+              nb = ns = 0;
+            }
+            const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)lane;
+            const int rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
+            const int rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(msp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msp, 0));
+            const int cb = __popcll(mb), cs = __popcll(msp);
+            if (cbox) w.list[nb + rb] = entry;
+            if (csph) w.list[kCandCap - ns - cs + rs] = entry;
+            nb += cb;
+            ns += cs;
+          }
+          if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
+        }
+      }
+    }
+    if (nb + ns) flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+
+    const unsigned long long best = w.best[lane];
+    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+    // record layout of the reference after its per-depth memset (pathtrace.cu:562):
+    // miss → t = -1 and zeros elsewhere.
+    const int leaf = hit ? (int)(uint32_t)best : 0;
+    hits.t[at] = hit ? __uint_as_float((uint32_t)(best >> 32)) : -1.0f;
+    hits.n[at] = hit ? w.rec[0 * 64 + lane] : 0.f;
+    hits.n[HS + at] = hit ? w.rec[1 * 64 + lane] : 0.f;
+    hits.n[2 * HS + at] = hit ? w.rec[2 * 64 + lane] : 0.f;
+    hits.mat[at] = hit ? geoms[nodes[leaf].geom].material : 0;
+    hits.p[at] = hit ? w.rec[3 * 64 + lane] : 0.f;
+    hits.p[HS + at] = hit ? w.rec[4 * 64 + lane] : 0.f;
+    hits.p[2 * HS + at] = hit ? w.rec[5 * 64 + lane] : 0.f;
   }
 }
 
@@ -396,25 +606,41 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t S = in.stride, HS = hits.stride, OS = out.stride;
   const int64_t FS = (int64_t)b.K * b.N;
+  // inputs of one path; the next group's are loaded while the current group is shaded
+  struct In {
+    int slot, hmat;
+    float ht;
+    f3 hn, hp, d, c;
+  };
+  auto load = [&](int i) {
+    In v;
+    const int64_t at = (int64_t)q * qs.cap + i;
+    v.slot = in.slot[at];
+    v.ht = hits.t[at];
+    v.hn = mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]);
+    v.hmat = hits.mat[at];
+    v.hp = mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]);
+    v.d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
+    v.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
+    return v;
+  };
+  In nx{};
+  if (r * 64 + lane < n_q) nx = load(r * 64 + lane);
   for (int j = r; j * 64 < n_q; j += wq) {
     const int i = j * 64 + lane;
     const bool valid = i < n_q;
+    const In cur = nx;
+    if ((j + wq) * 64 + lane < n_q) nx = load((j + wq) * 64 + lane);
     ShadeIO s;
     s.alive = false;
-    int slot = 0;
+    const int slot = cur.slot;
     if (valid) {
-      const int64_t at = (int64_t)q * qs.cap + i;
-      slot = in.slot[at];
       const int k = slot / b.N;
       const int p = slot - k * b.N;
-      const float ht = hits.t[at];
-      const f3 hn = mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]);
-      const int hmat = hits.mat[at];
-      const f3 hp = mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]);
       s.o = mk(0.f, 0.f, 0.f);
-      s.d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
-      s.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
-      shade_core(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, ht, hn, hmat, hp, s);
+      s.d = cur.d;
+      s.c = cur.c;
+      shade_core(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, cur.ht, cur.hn, cur.hmat, cur.hp, s);
       if (!s.alive) {  // retire: exactly one write per (iteration, pixel)
         final_rgb[slot] = s.c.x, final_rgb[FS + slot] = s.c.y, final_rgb[2 * FS + slot] = s.c.z;
       }
@@ -526,8 +752,14 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_generate, kBlock, 0);
       break;
     case kIntersect:
-      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true>, kBlock, round16(tbl));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false>, kBlock, 0);
+      if (tbl <= kLdsTableBytes)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true>, kBlock, round16(tbl) + kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
+      else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false>, kBlock, kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
+      break;
+    case kIntersectLegacy:
+      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true>, kBlock, round16(tbl));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false>, kBlock, 0);
       break;
     case kShade:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)));
@@ -543,13 +775,17 @@ void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const Batc
 }
 
 void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
-                      ptd::PathBuf paths, ptd::HitBuf hits) {
+                      ptd::PathBuf paths, ptd::HitBuf hits, bool legacy) {
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
-  if (bytes <= kLdsTableBytes) {
-    hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), round16(bytes), s, sc, qs, cnt_in, paths, hits);
-  } else {
-    hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), 0, s, sc, qs, cnt_in, paths, hits);
+  const bool in_lds = bytes <= kLdsTableBytes;
+  if (legacy) {
+    if (in_lds) hipLaunchKernelGGL(k_intersect_legacy<true>, dim3(grid), dim3(kBlock), round16(bytes), s, sc, qs, cnt_in, paths, hits);
+    else hipLaunchKernelGGL(k_intersect_legacy<false>, dim3(grid), dim3(kBlock), 0, s, sc, qs, cnt_in, paths, hits);
+    return;
   }
+  const int wave_lds = kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry);
+  if (in_lds) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), round16(bytes) + wave_lds, s, sc, qs, cnt_in, paths, hits);
+  else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), wave_lds, s, sc, qs, cnt_in, paths, hits);
 }
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,

@@ -87,7 +87,8 @@ typedef struct PtOptions {
   int32_t blocks_per_cu;   /* persistent grid = CUs * blocks_per_cu; 0 = auto    */
   int32_t time_kernels;    /* 1: bracket every computeIntersections launch with  */
                            /*    HIP events on the render stream (pt_get_stats)  */
-  int32_t reserved[9];
+  int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
+  int32_t reserved[8];
 } PtOptions;
 
 #define PT_MAX_DEPTH 64

@@ -46,6 +46,8 @@ def gpu_render(scene_path, res, spp, depth=None, first=1, **kw):
     ("cornell", (97, 61), 5, 1, {}),                                  # depth 1, odd sizes
     ("sphere", (256, 256), 16, 4, {}),                                # BASELINE config C1
     ("stress", (160, 90), 6, 8, {}),
+    ("stress", (160, 90), 6, 8, dict(legacy_traversal=True)),
+    ("cornell", (200, 120), 7, 8, dict(legacy_traversal=True)),
 ])
 def test_image_bit_exact_vs_oracle(scene_dir, oracle, scene, res, spp, depth, kw):
     img, st = gpu_render(scene_dir[scene], res, spp, depth, **kw)

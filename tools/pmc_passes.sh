@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect PMC counters for a short bench run, one rocprofv3 pass per counter group
+# (counters only: no --stats / trace domains besides --kernel-trace, per the pool rules).
+# usage: tools/pmc_passes.sh OUTDIR [bench args...]
+set -u
+OUT=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+mkdir -p "$R/$OUT"
+i=0
+for grp in \
+  "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_INSTS_SMEM" \
+  "FETCH_SIZE" \
+  "WRITE_SIZE" \
+  "TCC_HIT_sum TCC_MISS_sum" ; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$R/$OUT/pass$i" -o p -- python3 "$R/bench.py" --no-extras --no-kernel-events "$@" > "$R/$OUT/pass$i.json" 2> "$R/$OUT/pass$i.err" || echo "pass $i failed"
+done
+ls -R "$R/$OUT" | head -40
