@@ -75,6 +75,7 @@ def main() -> None:
     ap.add_argument("--queues", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--legacy-traversal", action="store_true", help="A/B: per-lane BVH walk kernel")
+    ap.add_argument("--debug-flags", type=int, default=0, help="profiling only (wrong results): 1 = intersect skips tracing")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket intersect launches with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and psnr (N=1 extras)")
     ap.add_argument("--save", type=str, default="", help="write the final image as PREFIX.png/.pfm")
@@ -110,7 +111,7 @@ def main() -> None:
         return capi.Renderer(scene, device=local_rank, pixel_begin=begin, pixel_count=count,
                              iters_per_batch=args.iters_per_batch, num_queues=args.queues,
                              blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels,
-                             legacy_traversal=args.legacy_traversal)
+                             legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags)
 
     def barrier():
         if world > 1:

@@ -68,6 +68,7 @@ struct Ctx {
   ptd::TopEntry* d_top = nullptr;
   int num_nodes = 0, num_top = 0;
   bool legacy = false;
+  int debug_flags = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
   float* d_final = nullptr;
@@ -184,7 +185,7 @@ ptk::SceneTables tables() {
   t.mats = g.d_mats;
   t.num_mats = (int)g.mats.size();
   t.top = g.d_top;
-  t.num_top = g.num_top;
+  t.num_top = (g.debug_flags & 1) ? 0 : g.num_top;
   return t;
 }
 
@@ -420,6 +421,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   build_top(ref_nodes, nodes, where, g.geoms, top);
   g.num_top = (int)top.size();
   g.legacy = opt.legacy_traversal != 0;
+  g.debug_flags = opt.debug_flags;
   std::vector<ptd::Geom> dg(g.geoms.size());
   for (size_t i = 0; i < g.geoms.size(); ++i) {
     std::memset(&dg[i], 0, sizeof(ptd::Geom));

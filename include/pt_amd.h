@@ -88,7 +88,9 @@ typedef struct PtOptions {
   int32_t time_kernels;    /* 1: bracket every computeIntersections launch with  */
                            /*    HIP events on the render stream (pt_get_stats)  */
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
-  int32_t reserved[8];
+  int32_t debug_flags;      /* profiling only, results are WRONG: bit0 intersect skips tracing (memory-side
+                               floor of the kernel), bit1 shade skips shading (every path retires) */
+  int32_t reserved[7];
 } PtOptions;
 
 #define PT_MAX_DEPTH 64
