@@ -75,6 +75,7 @@ def main() -> None:
     ap.add_argument("--queues", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--legacy-traversal", action="store_true", help="A/B: per-lane BVH walk kernel")
+    ap.add_argument("--unfused-primary", action="store_true", help="A/B: depth 0 as separate generate/intersect/shade launches")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling only (wrong results): 1 = intersect skips tracing")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket intersect launches with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and psnr (N=1 extras)")
@@ -111,7 +112,8 @@ def main() -> None:
         return capi.Renderer(scene, device=local_rank, pixel_begin=begin, pixel_count=count,
                              iters_per_batch=args.iters_per_batch, num_queues=args.queues,
                              blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels,
-                             legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags)
+                             legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags,
+                             unfused_primary=args.unfused_primary)
 
     def barrier():
         if world > 1:
@@ -141,12 +143,13 @@ def main() -> None:
 
     st = r.stats()
     live = np.array(st.live_rays[:DEPTH], dtype=np.float64)
+    timed = live[1:] if st.primary_fused else live  # depths covered by the timed computeIntersections launches
     isect_s = st.intersect_ms / 1e3
     if world > 1:  # roofline is per GPU: report rank 0's kernel (all ranks run the same kernel on their tile)
         pass
     roofline = None
     if st.intersect_launches > 0 and isect_s > 0:
-        achieved = ISECT_BYTES_PER_RAY * live.sum() / isect_s / 1e9
+        achieved = ISECT_BYTES_PER_RAY * timed.sum() / isect_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "intersect_traffic.json")
         if os.path.exists(tpath):
@@ -157,7 +160,8 @@ def main() -> None:
         roofline = {"bound": "hbm", "kernel": "k_intersect (computeIntersections)", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches": int(st.intersect_launches), "avg_launch_us": round(isect_s * 1e6 / st.intersect_launches, 3),
-                    "algorithmic_bytes_per_launch": round(ISECT_BYTES_PER_RAY * live.sum() / st.intersect_launches, 1),
+                    "algorithmic_bytes_per_launch": round(ISECT_BYTES_PER_RAY * timed.sum() / st.intersect_launches, 1),
+                    "depths_timed": "1..7 (depth 0 runs in the fused primary kernel)" if st.primary_fused else "0..7",
                     "live_rays_per_sample": round(float(live.sum()) / max(1, st.samples), 4)}
 
     samples = float(W) * H * args.steps

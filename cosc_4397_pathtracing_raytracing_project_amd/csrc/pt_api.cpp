@@ -69,6 +69,8 @@ struct Ctx {
   int num_nodes = 0, num_top = 0;
   bool legacy = false;
   int debug_flags = 0;
+  bool fuse_primary = true;
+  int grid_primary = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
   float* d_final = nullptr;
@@ -222,10 +224,18 @@ int run_batch(int iter_first, int kb) {
   b.trace_depth = g.depth;
   const size_t cnt_ints = (size_t)(g.depth + 1) * g.qs.Q * g.qs.cnt_stride;
   HIP_OK(hipMemsetAsync(g.d_cnt, 0, cnt_ints * sizeof(int32_t), g.stream));
-  ptk::launch_generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g.grid_gen), g.buf[0], g.d_cnt);
   const ptk::SceneTables sc = tables();
   const size_t per_depth = (size_t)g.qs.Q * g.qs.cnt_stride;
-  for (int d = 0; d < g.depth; ++d) {
+  int d0 = 0;
+  if (g.fuse_primary) {
+    // depth 0 in one launch; its survivors are the depth-1 input (buf[1], cnt[1])
+    ptk::launch_primary(g.stream, g.grid_primary, sc, g.dcam, b, queues_for(g.grid_primary), g.d_cnt, g.d_cnt + per_depth,
+                        g.buf[1], g.d_final);
+    d0 = 1;
+  } else {
+    ptk::launch_generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g.grid_gen), g.buf[0], g.d_cnt);
+  }
+  for (int d = d0; d < g.depth; ++d) {
     const int32_t* cin = g.d_cnt + per_depth * d;
     int32_t* cout = g.d_cnt + per_depth * (d + 1);
     EventPair ev{};
@@ -422,6 +432,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   g.num_top = (int)top.size();
   g.legacy = opt.legacy_traversal != 0;
   g.debug_flags = opt.debug_flags;
+  g.fuse_primary = !g.legacy && !opt.unfused_primary;
   std::vector<ptd::Geom> dg(g.geoms.size());
   for (size_t i = 0; i < g.geoms.size(); ++i) {
     std::memset(&dg[i], 0, sizeof(ptd::Geom));
@@ -455,6 +466,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
     g.grid_gen = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kGenerate, t));
     g.grid_isect = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
     g.grid_shade = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kShade, t));
+    g.grid_primary = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kPrimary, t));
   }
   // path state
   if (alloc_pathbuf(&g.buf[0], g.stride) || alloc_pathbuf(&g.buf[1], g.stride) || alloc_hitbuf(&g.hits, g.stride)) return -1;
@@ -547,6 +559,7 @@ int pt_get_stats(PtStats* out) {
   out->num_queues = g.qs.Q;
   out->iters_per_batch = g.K;
   out->device_bytes = g.device_bytes;
+  out->primary_fused = g.fuse_primary ? 1 : 0;
   return 0;
 }
 

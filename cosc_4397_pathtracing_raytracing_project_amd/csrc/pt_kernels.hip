@@ -94,6 +94,18 @@ PT_DEV void stage16(void* lds, const void* g, int bytes) {
 }
 
 // ───────────────────────────── generate ────────────────────────────────────
+// generateRayFromCamera (pathtrace.cu:270-286) for global pixel index p:
+// dir = normalize(view - right*pl.x*(x - W/2) - up*pl.y*(y - H/2)); no jitter, `iter` unused.
+PT_DEV f3 camera_dir(const ptd::Camera& cam, int p) {
+  const int x = p % cam.res_x, y = p / cam.res_x;
+  const float fx = (float)x - cam.res_x * 0.5f;
+  const float fy = (float)y - cam.res_y * 0.5f;
+  const f3 view = mk(cam.view[0], cam.view[1], cam.view[2]);
+  const f3 a = scl(scl(mk(cam.right[0], cam.right[1], cam.right[2]), cam.pl_x), fx);
+  const f3 c = scl(scl(mk(cam.up[0], cam.up[1], cam.up[2]), cam.pl_y), fy);
+  return normalize(sub(sub(view, a), c));
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo b, ptd::Queues qs, ptd::PathBuf out,
                                                      int32_t* __restrict__ cnt0) {
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -116,14 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
     if (gid < total) {
       const int k = (int)(gid / b.N);
       const int p = (int)(gid - (long long)k * b.N) + b.pixel_begin;  // global pixel index
-      const int x = p % cam.res_x, y = p / cam.res_x;
-      // dir = normalize(view - right*pl.x*(x - W/2) - up*pl.y*(y - H/2))
-      const float fx = (float)x - cam.res_x * 0.5f;
-      const float fy = (float)y - cam.res_y * 0.5f;
-      f3 view = mk(cam.view[0], cam.view[1], cam.view[2]);
-      f3 a = scl(scl(mk(cam.right[0], cam.right[1], cam.right[2]), cam.pl_x), fx);
-      f3 c = scl(scl(mk(cam.up[0], cam.up[1], cam.up[2]), cam.pl_y), fy);
-      f3 d = normalize(sub(sub(view, a), c));
+      const f3 d = camera_dir(cam, p);
       const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
       out.o[at] = cam.pos[0], out.o[S + at] = cam.pos[1], out.o[2 * S + at] = cam.pos[2];
       out.d[at] = d.x, out.d[S + at] = d.y, out.d[2 * S + at] = d.z;
@@ -368,6 +373,74 @@ PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f
   }
 }
 
+// Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
+// w.best[lane] holds the lane's (t bits << 32 | leaf) key (kNoHit if none) and w.rec its normal/point.
+PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
+                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane) {
+  const RayInv ri = ray_inv(d);
+  w.best[lane] = kNoHit;
+  int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
+
+  // top list: wave-uniform LDS reads (broadcast), entry e+1 fetched while entry e is tested
+  float4 A = top[0], B = top[1];
+  for (int e = 0; e < ntop; ++e) {
+    const float4 TA = A, TB = B;  // bmin.xyz, bmax.x | bmax.yz, idx, link
+    if (e + 1 < ntop) A = top[2 * e + 2], B = top[2 * e + 3];
+    const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
+    const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
+    const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
+    if (t_link < 0) {  // leaf entry: type is wave-uniform
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        if (nb + ns + 64 > kCandCap) {
+          flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+          nb = ns = 0;
+        }
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        const int cnt = __popcll(m);
+        const uint32_t entry = ((uint32_t)t_idx << 6) | (uint32_t)lane;
+        if (t_link == -2) {  // cube
+          if (pass) w.list[nb + rank] = entry;
+          nb += cnt;
+        } else {
+          if (pass) w.list[kCandCap - ns - cnt + rank] = entry;
+          ns += cnt;
+        }
+      }
+    } else {  // subtree [idx, link): stackless scan, lanes that did not enter idle
+      int cur = pass ? t_idx : t_link;
+      while (__ballot(cur < t_link)) {
+        const bool act = cur < t_link;
+        const int at_n = act ? cur : t_idx;
+        const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
+        const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
+        const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
+        const int g = __float_as_int(NB.w);
+        const bool cand = in && g >= 0;
+        const bool cbox = cand && geoms[g].type == 1;
+        const bool csph = cand && !cbox;
+        const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
+        if (mb | msp) {
+          if (nb + ns + 128 > kCandCap) {
+            flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+            nb = ns = 0;
+          }
+          const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)lane;
+          const int rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
+          const int rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(msp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msp, 0));
+          const int cb = __popcll(mb), cs = __popcll(msp);
+          if (cbox) w.list[nb + rb] = entry;
+          if (csph) w.list[kCandCap - ns - cs + rs] = entry;
+          nb += cb;
+          ns += cs;
+        }
+        if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
+      }
+    }
+  }
+  if (nb + ns) flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+}
+
 template <bool TABLES_IN_LDS>
 __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queues qs, const int32_t* __restrict__ cnt_in,
                                                       ptd::PathBuf paths, ptd::HitBuf hits) {
@@ -428,68 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
       no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
       nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
     }
-    const RayInv ri = ray_inv(d);
-    w.best[lane] = kNoHit;
-    int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
-
-    // top list: wave-uniform LDS reads (broadcast), entry e+1 fetched while entry e is tested
-    float4 A = top[0], B = top[1];
-    for (int e = 0; e < ntop; ++e) {
-      const float4 TA = A, TB = B;  // bmin.xyz, bmax.x | bmax.yz, idx, link
-      if (e + 1 < ntop) A = top[2 * e + 2], B = top[2 * e + 3];
-      const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
-      const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
-      const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
-      if (t_link < 0) {  // leaf entry: type is wave-uniform
-        const unsigned long long m = __ballot(pass);
-        if (m) {
-          if (nb + ns + 64 > kCandCap) {
-            flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
-            nb = ns = 0;
-          }
-          const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-          const int cnt = __popcll(m);
-          const uint32_t entry = ((uint32_t)t_idx << 6) | (uint32_t)lane;
-          if (t_link == -2) {  // cube
-            if (pass) w.list[nb + rank] = entry;
-            nb += cnt;
-          } else {
-            if (pass) w.list[kCandCap - ns - cnt + rank] = entry;
-            ns += cnt;
-          }
-        }
-      } else {  // subtree [idx, link): stackless scan, lanes that did not enter idle
-        int cur = pass ? t_idx : t_link;
-        while (__ballot(cur < t_link)) {
-          const bool act = cur < t_link;
-          const int at_n = act ? cur : t_idx;
-          const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
-          const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
-          const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
-          const int g = __float_as_int(NB.w);
-          const bool cand = in && g >= 0;
-          const bool cbox = cand && geoms[g].type == 1;
-          const bool csph = cand && !cbox;
-          const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
-          if (mb | msp) {
-            if (nb + ns + 128 > kCandCap) {
-              flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
-              nb = ns = 0;
-            }
-            const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)lane;
-            const int rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
-            const int rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(msp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msp, 0));
-            const int cb = __popcll(mb), cs = __popcll(msp);
-            if (cbox) w.list[nb + rb] = entry;
-            if (csph) w.list[kCandCap - ns - cs + rs] = entry;
-            nb += cb;
-            ns += cs;
-          }
-          if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
-        }
-      }
-    }
-    if (nb + ns) flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
 
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -523,54 +535,80 @@ struct ShadeIO {
   f3 o, d, c;
   bool alive;
 };
-// One thread of shadeAndExtendRays for a LIVE path (remainingBounces > 0 is implied:
-// a live path at depth d has exactly trace_depth - d bounces left).  On return
-// `alive == false` means the path retires with colour s.c; for a miss the sky factor
-// has been applied (trace_depth - depth) times, which is what the reference's repeated
-// passes over dead paths do (pathtrace.cu:356-366).
-PT_DEV void shade_core(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, int iter, int pixel, float ht,
-                       f3 hn, int hmat, f3 hp, ShadeIO& s) {
+// shadeAndExtendRays (pathtrace.cu:336-437) for a LIVE path, split in two so that the wave can
+// publish its survivor count (one atomic) while the expensive direction sampling still runs:
+//   shade_decide  everything that determines whether the path survives and its new throughput:
+//                 miss / emitter / Russian roulette / specular-vs-diffuse choice / colour product.
+//                 Consumes the RNG draws the reference consumes up to that point, in its order.
+//   shade_bounce  the new ray of a surviving path (remaining draws, sin/cos/acos).
+// A live path at depth d has exactly trace_depth - d bounces left, so remainingBounces is implied.
+// On `alive == false` the path retires with colour s.c; for a miss the sky factor has been applied
+// (trace_depth - depth) times, which is what the reference's repeated passes over dead paths do
+// (pathtrace.cu:356-366).
+struct Bounce {
+  uint32_t rng_x;   // minstd state after the draws consumed by shade_decide
+  int kind;         // 0 none, 1 specular, 2 diffuse
+  float roughness;
+};
+PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, int iter, int pixel, float ht,
+                           int hmat, ShadeIO& s) {
+  Bounce bo;
+  bo.kind = 0;
+  bo.rng_x = 1u;
+  bo.roughness = 0.f;
+  s.alive = false;
   if (ht < 0.0f) {
     const f3 sky = sky_factor(s.d);
     for (int k = depth; k < trace_depth; ++k) s.c = mul(s.c, sky);
-    s.alive = false;
-    return;
+    return bo;
   }
   MinStd rng(seed_hash(iter, pixel, depth));
   const ptd::Mat* m = mats + hmat;
   const f3 mcolor = mk(m->color[0], m->color[1], m->color[2]);
   if (m->emittance > 0.0f) {
     s.c = mul(s.c, scl(mcolor, m->emittance));
-    s.alive = false;
-    return;
+    return bo;
   }
   if (depth > 3) {  // Russian roulette
     const float q = __builtin_fmaxf(mcolor.x, __builtin_fmaxf(mcolor.y, mcolor.z));
-    if (rng.u01() > q) {
-      s.alive = false;
-      return;
-    }
+    if (rng.u01() > q) return bo;
     s.c = mk(s.c.x / q, s.c.y / q, s.c.z / q);
   }
   const float reflectivity = m->reflective;
-  const float roughness = 1.0f - m->refractive;
-  f3 ndir;
+  bo.roughness = 1.0f - m->refractive;
   if (reflectivity > 0.0f && rng.u01() < reflectivity) {
+    bo.kind = 1;
+    s.c = mul(s.c, mk(m->spec[0], m->spec[1], m->spec[2]));
+  } else {
+    bo.kind = 2;
+    s.c = mul(s.c, mcolor);
+  }
+  bo.rng_x = rng.x;
+  // remainingBounces-- : the path survives unless this was its last allowed bounce (its new ray
+  // would never be traced, so it is not computed)
+  s.alive = (depth + 1) < trace_depth;
+  return bo;
+}
+PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
+  MinStd rng(1u);
+  rng.x = bo.rng_x;
+  f3 ndir;
+  if (bo.kind == 1) {
     // reflect(): incident - 2*dot(incident, normal)*normal
     f3 rdir = sub(s.d, scl(hn, 2.0f * dot(s.d, hn)));
-    if (roughness > 0.0f) {
+    if (bo.roughness > 0.0f) {
       f3 tangent, bitangent;
       local_frame(rdir, tangent, bitangent);
       // M_PI is double in the reference: these products are evaluated in double
-      const float angle = (float)((double)(roughness * rng.u01()) * 3.14159265358979323846 * (double)0.5f);
-      const float sa = ptmath::sinf32(angle);
+      const float angle = (float)((double)(bo.roughness * rng.u01()) * 3.14159265358979323846 * (double)0.5f);
+      float sa, ca;
+      ptmath::sincosf32(angle, &sa, &ca);
       const float x = (float)((double)sa * ptmath::cos64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
-      const float y = ptmath::cosf32(angle);
+      const float y = ca;
       const float z = (float)((double)sa * ptmath::sin64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
       rdir = normalize(add(add(scl(tangent, x), scl(rdir, y)), scl(bitangent, z)));
     }
     ndir = rdir;
-    s.c = mul(s.c, mk(m->spec[0], m->spec[1], m->spec[2]));
   } else {
     const float u1 = rng.u01();
     const float u2 = rng.u01();
@@ -578,17 +616,51 @@ PT_DEV void shade_core(const ptd::Mat* __restrict__ mats, int trace_depth, int d
     local_frame(hn, tangent, bitangent);
     const float theta = ptmath::acosf32(__builtin_sqrtf(1.0f - u1));
     const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)u2);
-    const float st = ptmath::sinf32(theta);
-    const float x = st * ptmath::cosf32(phi);
-    const float y = ptmath::cosf32(theta);
-    const float z = st * ptmath::sinf32(phi);
+    float st, ct, sp, cp;
+    ptmath::sincosf32(theta, &st, &ct);
+    ptmath::sincosf32(phi, &sp, &cp);
+    const float x = st * cp;
+    const float y = ct;
+    const float z = st * sp;
     ndir = normalize(add(add(scl(tangent, x), scl(hn, y)), scl(bitangent, z)));
-    s.c = mul(s.c, mcolor);
   }
   s.o = add(hp, scl(hn, 0.001f));
   s.d = ndir;
-  // remainingBounces-- : the path survives unless this was its last allowed bounce
-  s.alive = (depth + 1) < trace_depth;
+}
+
+// Retirement + wave-level compaction shared by k_shade and k_primary.
+//   1. dead lanes write their final colour (exactly one write per (iteration, pixel));
+//   2. ballot + popcount, lane 0 reserves room in the queue with ONE atomic per wave — issued here,
+//      before shade_bounce, so its round trip hides behind the trigonometry;
+//   3. caller runs shade_bounce, then emit_survivors stores the compacted paths.
+struct Reservation {
+  unsigned long long live;
+  int base;
+};
+PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int slot, int64_t FS, float* __restrict__ final_rgb,
+                                      int32_t* __restrict__ counter, int lane) {
+  if (valid && !s.alive) {
+    final_rgb[slot] = s.c.x, final_rgb[FS + slot] = s.c.y, final_rgb[2 * FS + slot] = s.c.z;
+  }
+  Reservation r;
+  r.live = __ballot(valid && s.alive);
+  r.base = 0;
+  if (r.live && lane == 0) r.base = atomicAdd(counter, __popcll(r.live));
+  return r;
+}
+PT_DEV void emit_survivors(const Reservation& r, bool alive, const ShadeIO& s, int slot, int64_t qbase, ptd::PathBuf out) {
+  if (r.live) {
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(r.live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)r.live, 0));
+    const int base = __builtin_amdgcn_readfirstlane(r.base);
+    if (alive) {
+      const int64_t OS = out.stride;
+      const int64_t to = qbase + base + rank;
+      out.o[to] = s.o.x, out.o[OS + to] = s.o.y, out.o[2 * OS + to] = s.o.z;
+      out.d[to] = s.d.x, out.d[OS + to] = s.d.y, out.d[2 * OS + to] = s.d.z;
+      out.c[to] = s.c.x, out.c[OS + to] = s.c.y, out.c[2 * OS + to] = s.c.z;
+      out.slot[to] = slot;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
@@ -604,17 +676,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t S = in.stride, HS = hits.stride, OS = out.stride;
+  const int64_t S = in.stride, HS = hits.stride;
   const int64_t FS = (int64_t)b.K * b.N;
-  // inputs of one path; the next group's are loaded while the current group is shaded
+  const int64_t qbase = (int64_t)q * qs.cap;
+  // inputs of one path; the next group's are loaded (branch-free, index clamped into the queue's own
+  // region) while the current group is shaded
   struct In {
     int slot, hmat;
     float ht;
     f3 hn, hp, d, c;
   };
+  const int last = qs.cap - 64 + lane;
   auto load = [&](int i) {
     In v;
-    const int64_t at = (int64_t)q * qs.cap + i;
+    const int64_t at = qbase + min(i, last);
     v.slot = in.slot[at];
     v.ht = hits.t[at];
     v.hn = mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]);
@@ -624,43 +699,124 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     v.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
     return v;
   };
-  In nx{};
-  if (r * 64 + lane < n_q) nx = load(r * 64 + lane);
+  In nx = load(r * 64 + lane);
   for (int j = r; j * 64 < n_q; j += wq) {
     const int i = j * 64 + lane;
     const bool valid = i < n_q;
     const In cur = nx;
-    if ((j + wq) * 64 + lane < n_q) nx = load((j + wq) * 64 + lane);
+    nx = load((j + wq) * 64 + lane);
     ShadeIO s;
+    s.o = mk(0.f, 0.f, 0.f);
+    s.d = cur.d;
+    s.c = cur.c;
     s.alive = false;
     const int slot = cur.slot;
+    Bounce bo;
+    bo.kind = 0;
     if (valid) {
       const int k = slot / b.N;
       const int p = slot - k * b.N;
-      s.o = mk(0.f, 0.f, 0.f);
-      s.d = cur.d;
-      s.c = cur.c;
-      shade_core(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, cur.ht, cur.hn, cur.hmat, cur.hp, s);
-      if (!s.alive) {  // retire: exactly one write per (iteration, pixel)
-        final_rgb[slot] = s.c.x, final_rgb[FS + slot] = s.c.y, final_rgb[2 * FS + slot] = s.c.z;
-      }
+      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, cur.ht, cur.hmat, s);
     }
-    // wave-level compaction: ballot + prefix popcount, one atomic per wave
-    const unsigned long long live = __ballot(valid && s.alive);
-    if (live) {
-      const int nlive = __popcll(live);
-      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0));
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&cnt_out[(size_t)q * qs.cnt_stride], nlive);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (valid && s.alive) {
-        const int64_t to = (int64_t)q * qs.cap + base + rank;
-        out.o[to] = s.o.x, out.o[OS + to] = s.o.y, out.o[2 * OS + to] = s.o.z;
-        out.d[to] = s.d.x, out.d[OS + to] = s.d.y, out.d[2 * OS + to] = s.d.z;
-        out.c[to] = s.c.x, out.c[OS + to] = s.c.y, out.c[2 * OS + to] = s.c.z;
-        out.slot[to] = slot;
-      }
+    const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    const bool alive = valid && s.alive;
+    if (alive) shade_bounce(bo, cur.hn, cur.hp, s);
+    emit_survivors(res, alive, s, slot, qbase, out);
+  }
+}
+
+// ── depth 0 fused: generateRayFromCamera + computeIntersections + shadeAndExtendRays ────────
+// Primary rays are a pure function of the sample id, so depth 0 needs no path state in memory at
+// all: the ray is built in registers, traced with the same wave-cooperative search, shaded, and
+// only its outcome is written — the survivor's new ray into the depth-1 queues or the retired
+// colour.  That removes the generate launch and ~190 B/sample of HBM round trips (40 B ray state
+// written + 24 B read, 32 B hit record written + read, 28 B path state re-read) at the one depth
+// where every sample is alive.  Also writes the per-queue sample counts of depth 0 (statistics).
+template <bool TABLES_IN_LDS>
+__global__ __launch_bounds__(kBlock) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
+                                                    int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
+                                                    ptd::PathBuf out, float* __restrict__ final_rgb) {
+  extern __shared__ float4 lds_raw[];
+  char* lds = reinterpret_cast<char*>(lds_raw);
+  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
+  stage16(lds, sc.top, nb_top);
+  stage16(lds + nb_top, sc.mats, nb_mats);
+  const float4* top = reinterpret_cast<const float4*>(lds);
+  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
+  const ptd::Node* nodes = sc.nodes;
+  const ptd::Geom* geoms = sc.geoms;
+  int tbl = nb_top + nb_mats;
+  if (TABLES_IN_LDS) {
+    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
+    stage16(lds + tbl, sc.nodes, nb_nodes);
+    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
+    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
+    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
+    tbl += nb_nodes + nb_geoms;
+  }
+  __syncthreads();
+  const int wib = threadIdx.x >> 6;
+  WaveLds w;
+  {
+    char* base = lds + tbl + wib * kWaveLds;
+    w.best = reinterpret_cast<unsigned long long*>(base);
+    w.rec = reinterpret_cast<float*>(base + 64 * 8);
+    w.list = reinterpret_cast<uint32_t*>(base + 64 * 8 + 7 * 64 * 4);
+  }
+  const int ntop = sc.num_top;
+  const int wave = blockIdx.x * kWavesPerBlock + wib;
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  // samples are dealt to the queues in 64-sample chunks, round-robin (same map as k_generate)
+  const long long total = (long long)b.K * b.N;
+  const long long chunks = (total + 63) / 64;
+  const long long my_chunks = (chunks - q + qs.Q - 1) / qs.Q;
+  if (r == 0 && lane == 0) {
+    long long n = 0;
+    if (my_chunks > 0) {
+      const long long last = q + (my_chunks - 1) * qs.Q;
+      n = (my_chunks - 1) * 64 + (last == chunks - 1 ? total - last * 64 : 64);
     }
+    cnt0[(size_t)q * qs.cnt_stride] = (int32_t)n;
+  }
+  const int64_t FS = total;
+  const int64_t qbase = (int64_t)q * qs.cap;
+  const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+  for (long long j = r; j < my_chunks; j += wq) {
+    const long long gid = (j * qs.Q + q) * 64 + lane;
+    const bool valid = gid < total;
+    const int slot = (int)(valid ? gid : total - 1);
+    const int k = slot / b.N;
+    const int p = slot - k * b.N + b.pixel_begin;  // global pixel index
+    const f3 d = camera_dir(cam, p);
+    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
+    const unsigned long long best = w.best[lane];
+    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+    ShadeIO s;
+    s.o = o;
+    s.d = d;
+    s.c = mk(1.0f, 1.0f, 1.0f);
+    s.alive = false;
+    Bounce bo;
+    bo.kind = 0;
+    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+    if (valid) {
+      float ht = -1.0f;
+      int hmat = 0;
+      if (hit) {
+        ht = __uint_as_float((uint32_t)(best >> 32));
+        hmat = geoms[nodes[(uint32_t)best].geom].material;
+        hn = mk(w.rec[0 * 64 + lane], w.rec[1 * 64 + lane], w.rec[2 * 64 + lane]);
+        hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
+      }
+      bo = shade_decide(mats, b.trace_depth, 0, b.iter_first + k, p, ht, hmat, s);
+    }
+    const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    const bool alive = valid && s.alive;
+    if (alive) shade_bounce(bo, hn, hp, s);
+    emit_survivors(res, alive, s, slot, qbase, out);
   }
 }
 
@@ -680,9 +836,10 @@ __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trac
     s.d = mk(paths.d[at], paths.d[S + at], paths.d[2 * S + at]);
     s.c = mk(paths.c[at], paths.c[S + at], paths.c[2 * S + at]);
     s.alive = false;
-    shade_core(mats, trace_depth, depth, iter[at], pixel[at], hits.t[at],
-               mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]), hits.mat[at],
-               mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]), s);
+    const Bounce bo = shade_decide(mats, trace_depth, depth, iter[at], pixel[at], hits.t[at], hits.mat[at], s);
+    // the stage reports the bounce ray whenever one is sampled (also at the last depth), like the reference
+    if (bo.kind) shade_bounce(bo, mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]),
+                              mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]), s);
     paths.o[at] = s.o.x, paths.o[S + at] = s.o.y, paths.o[2 * S + at] = s.o.z;
     paths.d[at] = s.d.x, paths.d[S + at] = s.d.y, paths.d[2 * S + at] = s.d.z;
     paths.c[at] = s.c.x, paths.c[S + at] = s.c.y, paths.c[2 * S + at] = s.c.z;
@@ -743,6 +900,7 @@ inline int round16(int x) { return (x + 15) & ~15; }
 }  // namespace
 
 // ───────────────────────────── launch wrappers ─────────────────────────────
+static int primary_lds_bytes(const SceneTables& sc, bool in_lds);
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
   int n = 0;
   hipError_t e = hipSuccess;
@@ -760,6 +918,10 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
     case kIntersectLegacy:
       if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true>, kBlock, round16(tbl));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false>, kBlock, 0);
+      break;
+    case kPrimary:
+      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, primary_lds_bytes(sc, true));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, primary_lds_bytes(sc, false));
       break;
     case kShade:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)));
@@ -786,6 +948,19 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
   const int wave_lds = kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry);
   if (in_lds) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), round16(bytes) + wave_lds, s, sc, qs, cnt_in, paths, hits);
   else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), wave_lds, s, sc, qs, cnt_in, paths, hits);
+}
+
+static int primary_lds_bytes(const SceneTables& sc, bool in_lds) {
+  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * kWaveLds;
+  if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
+  return bytes;
+}
+void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
+                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float* final_rgb) {
+  const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
+  const bool in_lds = bytes <= kLdsTableBytes;
+  if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, false), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
 }
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,

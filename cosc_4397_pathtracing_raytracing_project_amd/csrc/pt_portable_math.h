@@ -88,6 +88,18 @@ PT_HD double cos64(double x) {
   return ((q + 1) & 2) ? -v : v;
 }
 
+// sin and cos of the same argument with one reduction and one pair of kernels; bit-identical to
+// calling sin64 and cos64 separately (same operations on the same values).
+PT_HD void sincos64(double x, double* s_out, double* c_out) {
+  int q;
+  double r = reduce_pio2(x, &q);
+  double s = ksin(r), c = kcos(r);
+  double vs = (q & 1) ? c : s;
+  double vc = (q & 1) ? s : c;
+  *s_out = (q & 2) ? -vs : vs;
+  *c_out = ((q + 1) & 2) ? -vc : vc;
+}
+
 // acos(x) for x in [-1, 1]; NaN outside.  fdlibm rational approximation of
 // asin on [0, 0.5] plus the half-angle identities.
 PT_HD double acos_rational(double z) {
@@ -131,5 +143,11 @@ PT_HD double acos64(double x) {
 PT_HD float sinf32(float x) { return (float)sin64((double)x); }
 PT_HD float cosf32(float x) { return (float)cos64((double)x); }
 PT_HD float acosf32(float x) { return (float)acos64((double)x); }
+PT_HD void sincosf32(float x, float* s, float* c) {
+  double ds, dc;
+  sincos64((double)x, &ds, &dc);
+  *s = (float)ds;
+  *c = (float)dc;
+}
 
 }  // namespace ptmath

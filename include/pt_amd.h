@@ -90,7 +90,9 @@ typedef struct PtOptions {
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
   int32_t debug_flags;      /* profiling only, results are WRONG: bit0 intersect skips tracing (memory-side
                                floor of the kernel), bit1 shade skips shading (every path retires) */
-  int32_t reserved[7];
+  int32_t unfused_primary;  /* 1: run depth 0 as generate + intersect + shade launches instead of the fused
+                               primary kernel (A/B and stage-parity runs) */
+  int32_t reserved[6];
 } PtOptions;
 
 #define PT_MAX_DEPTH 64
@@ -102,6 +104,9 @@ typedef struct PtStats {
   double render_ms;                   /* HIP-event time of all pt_render calls           */
   int32_t num_cus, grid_blocks, num_queues, iters_per_batch;
   int64_t device_bytes;               /* device memory held by the renderer              */
+  int32_t primary_fused;              /* 1: depth 0 ran in the fused primary kernel, so the timed
+                                         computeIntersections launches cover depths >= 1 only   */
+  int32_t reserved;
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,

@@ -48,6 +48,9 @@ def gpu_render(scene_path, res, spp, depth=None, first=1, **kw):
     ("stress", (160, 90), 6, 8, {}),
     ("stress", (160, 90), 6, 8, dict(legacy_traversal=True)),
     ("cornell", (200, 120), 7, 8, dict(legacy_traversal=True)),
+    ("cornell", (200, 120), 7, 8, dict(unfused_primary=True, iters_per_batch=2)),
+    ("stress", (160, 90), 6, 8, dict(unfused_primary=True)),
+    ("sphere", (256, 256), 16, 4, dict(unfused_primary=True)),
 ])
 def test_image_bit_exact_vs_oracle(scene_dir, oracle, scene, res, spp, depth, kw):
     img, st = gpu_render(scene_dir[scene], res, spp, depth, **kw)

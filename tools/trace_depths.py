@@ -6,7 +6,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 seq, cur = [], None
 for r in rows:
     n = r["Kernel_Name"]
-    s = "isect" if "k_intersect" in n else "shade" if "k_shade" in n else "gen" if "k_generate" in n else "gather" if "k_gather" in n else "other"
+    s = "gen" if "k_primary" in n else "isect" if "k_intersect" in n else "shade" if "k_shade" in n else "gen" if "k_generate" in n else "gather" if "k_gather" in n else "other"
     if s == "gen":
         cur = []
         seq.append(cur)
@@ -14,6 +14,7 @@ for r in rows:
         cur.append((s, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 D = max(len([x for x in b if x[0] == "isect"]) for b in seq)
 full = [b for b in seq if len([x for x in b if x[0] == "isect"]) == D][2:]
+print("first kernel of batch:", "k_primary/k_generate")
 ti = ts = 0
 for i in range(D):
     di = statistics.median([[x for x in b if x[0] == "isect"][i][1] for b in full])
