@@ -53,6 +53,23 @@ PT_DEV f3 mulMV(const float* m, f3 v, float w) {
 
 PT_DEV int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Exact a / n and a % n for 0 <= a < 2^30 and quotients below 2^15 (sample ids / tile pixels,
+// pixel index / image width): float estimate + one correction step either way, ~10 VALU instead of
+// the ~35 of a 32-bit integer division.  inv_n = 1.0f / n computed once per kernel.
+PT_DEV void divmod(int a, int n, float inv_n, int& q, int& r) {
+  int k = (int)((float)a * inv_n);
+  int rem = a - k * n;
+  if (rem < 0) {
+    rem += n;
+    --k;
+  } else if (rem >= n) {
+    rem -= n;
+    ++k;
+  }
+  q = k;
+  r = rem;
+}
+
 // ───────────────────────────── RNG ──────────────────────────────────────────
 PT_DEV uint32_t utilhash(uint32_t a) {  // intersections.h:12-20
   a = (a + 0x7ed55d16u) + (a << 12);
@@ -96,8 +113,9 @@ PT_DEV void stage16(void* lds, const void* g, int bytes) {
 // ───────────────────────────── generate ────────────────────────────────────
 // generateRayFromCamera (pathtrace.cu:270-286) for global pixel index p:
 // dir = normalize(view - right*pl.x*(x - W/2) - up*pl.y*(y - H/2)); no jitter, `iter` unused.
-PT_DEV f3 camera_dir(const ptd::Camera& cam, int p) {
-  const int x = p % cam.res_x, y = p / cam.res_x;
+PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p) {
+  int x, y;
+  divmod(p, cam.res_x, inv_w, y, x);
   const float fx = (float)x - cam.res_x * 0.5f;
   const float fy = (float)y - cam.res_y * 0.5f;
   const f3 view = mk(cam.view[0], cam.view[1], cam.view[2]);
@@ -111,6 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const float inv_n = 1.0f / (float)b.N, inv_w = 1.0f / (float)cam.res_x;
   const long long total = (long long)b.K * b.N;
   const long long chunks = (total + 63) / 64;           // 64-sample chunks, dealt round-robin to queues
   const long long my_chunks = (chunks - q + qs.Q - 1) / qs.Q;  // chunks q, q+Q, ...
@@ -126,9 +145,10 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
   for (long long j = r; j < my_chunks; j += wq) {
     const long long gid = (j * qs.Q + q) * 64 + lane;
     if (gid < total) {
-      const int k = (int)(gid / b.N);
-      const int p = (int)(gid - (long long)k * b.N) + b.pixel_begin;  // global pixel index
-      const f3 d = camera_dir(cam, p);
+      int k, pl;
+      divmod((int)gid, b.N, inv_n, k, pl);
+      const int p = pl + b.pixel_begin;  // global pixel index
+      const f3 d = camera_dir(cam, inv_w, p);
       const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
       out.o[at] = cam.pos[0], out.o[S + at] = cam.pos[1], out.o[2 * S + at] = cam.pos[2];
       out.d[at] = d.x, out.d[S + at] = d.y, out.d[2 * S + at] = d.z;
@@ -603,9 +623,12 @@ PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
       const float angle = (float)((double)(bo.roughness * rng.u01()) * 3.14159265358979323846 * (double)0.5f);
       float sa, ca;
       ptmath::sincosf32(angle, &sa, &ca);
+      __builtin_amdgcn_sched_barrier(0);
       const float x = (float)((double)sa * ptmath::cos64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
+      __builtin_amdgcn_sched_barrier(0);
       const float y = ca;
       const float z = (float)((double)sa * ptmath::sin64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
+      __builtin_amdgcn_sched_barrier(0);
       rdir = normalize(add(add(scl(tangent, x), scl(rdir, y)), scl(bitangent, z)));
     }
     ndir = rdir;
@@ -614,11 +637,16 @@ PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
     const float u2 = rng.u01();
     f3 tangent, bitangent;
     local_frame(hn, tangent, bitangent);
+    // scheduling fences keep the three double-precision evaluations from being interleaved: each
+    // needs ~16 VGPRs of f64 temporaries, and overlapping them costs a whole occupancy step
     const float theta = ptmath::acosf32(__builtin_sqrtf(1.0f - u1));
+    __builtin_amdgcn_sched_barrier(0);
     const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)u2);
     float st, ct, sp, cp;
     ptmath::sincosf32(theta, &st, &ct);
+    __builtin_amdgcn_sched_barrier(0);
     ptmath::sincosf32(phi, &sp, &cp);
+    __builtin_amdgcn_sched_barrier(0);
     const float x = st * cp;
     const float y = ct;
     const float z = st * sp;
@@ -679,6 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int64_t S = in.stride, HS = hits.stride;
   const int64_t FS = (int64_t)b.K * b.N;
   const int64_t qbase = (int64_t)q * qs.cap;
+  const float inv_n = 1.0f / (float)b.N;
   // inputs of one path; the next group's are loaded (branch-free, index clamped into the queue's own
   // region) while the current group is shaded
   struct In {
@@ -714,8 +743,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     Bounce bo;
     bo.kind = 0;
     if (valid) {
-      const int k = slot / b.N;
-      const int p = slot - k * b.N;
+      int k, p;
+      divmod(slot, b.N, inv_n, k, p);
       bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, cur.ht, cur.hmat, s);
     }
     const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
@@ -733,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
 // written + 24 B read, 32 B hit record written + read, 28 B path state re-read) at the one depth
 // where every sample is alive.  Also writes the per-queue sample counts of depth 0 (statistics).
 template <bool TABLES_IN_LDS>
-__global__ __launch_bounds__(kBlock) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
+__global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
                                                     int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
                                                     ptd::PathBuf out, float* __restrict__ final_rgb) {
   extern __shared__ float4 lds_raw[];
@@ -783,14 +812,16 @@ __global__ __launch_bounds__(kBlock) void k_primary(SceneTables sc, ptd::Camera 
   }
   const int64_t FS = total;
   const int64_t qbase = (int64_t)q * qs.cap;
+  const float inv_n = 1.0f / (float)b.N, inv_w = 1.0f / (float)cam.res_x;
   const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
   for (long long j = r; j < my_chunks; j += wq) {
     const long long gid = (j * qs.Q + q) * 64 + lane;
     const bool valid = gid < total;
     const int slot = (int)(valid ? gid : total - 1);
-    const int k = slot / b.N;
-    const int p = slot - k * b.N + b.pixel_begin;  // global pixel index
-    const f3 d = camera_dir(cam, p);
+    int k, pl;
+    divmod(slot, b.N, inv_n, k, pl);
+    const int p = pl + b.pixel_begin;  // global pixel index
+    const f3 d = camera_dir(cam, inv_w, p);
     trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
