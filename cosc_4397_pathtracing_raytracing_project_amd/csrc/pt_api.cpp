@@ -398,7 +398,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   // batch size: enough paths in flight to fill the chip a few times over; slots are int32
   int K = opt.iters_per_batch;
   if (K <= 0) {
-    const int64_t target = 4ll << 20;  // ~4 M paths per batch
+    const int64_t target = 12ll << 20;  // ~12 M paths per batch (6 iterations of 1920x1080)
     K = (int)std::max<int64_t>(1, std::min<int64_t>(64, (target + g.N - 1) / g.N));
   }
   while ((int64_t)K * g.N > (1ll << 30) && K > 1) --K;
