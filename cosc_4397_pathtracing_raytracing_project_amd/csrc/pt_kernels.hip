@@ -541,8 +541,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
 
 // ───────────────────────────── shade ───────────────────────────────────────
 PT_DEV void local_frame(f3 n, f3& tangent, f3& bitangent) {  // pathtrace.cu:216-223
-  if (__builtin_fabsf(n.x) > __builtin_fabsf(n.y)) tangent = normalize(mk(n.z, 0.f, -n.x));
-  else tangent = normalize(mk(0.f, -n.z, n.y));
+  const bool a = __builtin_fabsf(n.x) > __builtin_fabsf(n.y);
+  tangent = normalize(a ? mk(n.z, 0.f, -n.x) : mk(0.f, -n.z, n.y));
   bitangent = cross(n, tangent);
 }
 PT_DEV f3 sky_factor(f3 dir) {  // pathtrace.cu:360-362: skyColor * 0.5f
@@ -610,50 +610,42 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
   return bo;
 }
 PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
+  // The specular branch (pathtrace.cu:402-422) and the diffuse branch (:424-435, :225-238) have the
+  // same shape — a frame around an axis f, three trigonometric evaluations, normalize(t*x + f*y + b*z)
+  // — so both are evaluated by ONE instruction stream with per-lane operands instead of two divergent
+  // branches executed back to back (a wave almost always holds both kinds).  Operations and their
+  // order per lane are exactly the reference's:
+  //   specular: f = reflect(d, n); angle = float(roughness*u1 * M_PI * 0.5f) [double product];
+  //             x = float(sin(angle) * cos(2.0f*M_PI*u2)) [double], y = cos(angle),
+  //             z = float(sin(angle) * sin(2.0f*M_PI*u3)) [double]
+  //   diffuse:  f = n; theta = acos(sqrt(1-u1)); phi = float(2.0f*M_PI*u2) [double product];
+  //             x = sin(theta)*cos(phi), y = cos(theta), z = sin(theta)*sin(phi)   [float]
+  const double kPi = 3.14159265358979323846;
   MinStd rng(1u);
   rng.x = bo.rng_x;
-  f3 ndir;
-  if (bo.kind == 1) {
-    // reflect(): incident - 2*dot(incident, normal)*normal
-    f3 rdir = sub(s.d, scl(hn, 2.0f * dot(s.d, hn)));
-    if (bo.roughness > 0.0f) {
-      f3 tangent, bitangent;
-      local_frame(rdir, tangent, bitangent);
-      // M_PI is double in the reference: these products are evaluated in double
-      const float angle = (float)((double)(bo.roughness * rng.u01()) * 3.14159265358979323846 * (double)0.5f);
-      float sa, ca;
-      ptmath::sincosf32(angle, &sa, &ca);
-      __builtin_amdgcn_sched_barrier(0);
-      const float x = (float)((double)sa * ptmath::cos64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
-      __builtin_amdgcn_sched_barrier(0);
-      const float y = ca;
-      const float z = (float)((double)sa * ptmath::sin64((double)2.0f * 3.14159265358979323846 * (double)rng.u01()));
-      __builtin_amdgcn_sched_barrier(0);
-      rdir = normalize(add(add(scl(tangent, x), scl(rdir, y)), scl(bitangent, z)));
-    }
-    ndir = rdir;
-  } else {
-    const float u1 = rng.u01();
-    const float u2 = rng.u01();
-    f3 tangent, bitangent;
-    local_frame(hn, tangent, bitangent);
-    // scheduling fences keep the three double-precision evaluations from being interleaved: each
-    // needs ~16 VGPRs of f64 temporaries, and overlapping them costs a whole occupancy step
-    const float theta = ptmath::acosf32(__builtin_sqrtf(1.0f - u1));
-    __builtin_amdgcn_sched_barrier(0);
-    const float phi = (float)((double)2.0f * 3.14159265358979323846 * (double)u2);
-    float st, ct, sp, cp;
-    ptmath::sincosf32(theta, &st, &ct);
-    __builtin_amdgcn_sched_barrier(0);
-    ptmath::sincosf32(phi, &sp, &cp);
-    __builtin_amdgcn_sched_barrier(0);
-    const float x = st * cp;
-    const float y = ct;
-    const float z = st * sp;
-    ndir = normalize(add(add(scl(tangent, x), scl(hn, y)), scl(bitangent, z)));
-  }
+  const bool spec = bo.kind == 1;
+  const float r1 = rng.u01(), r2 = rng.u01(), r3 = rng.u01();  // diffuse consumes only two; the engine dies here
+  const f3 refl = sub(s.d, scl(hn, 2.0f * dot(s.d, hn)));     // reflect(): incident - 2*dot(incident, n)*n
+  const f3 f = spec ? refl : hn;
+  const float angle = (float)((double)(bo.roughness * r1) * kPi * (double)0.5f);
+  const float theta = ptmath::acosf32(__builtin_sqrtf(1.0f - r1));
+  const float phi = (float)((double)2.0f * kPi * (double)r2);
+  const float X = spec ? angle : theta;
+  const double Y1 = spec ? (double)2.0f * kPi * (double)r2 : (double)phi;
+  const double Y2 = spec ? (double)2.0f * kPi * (double)r3 : (double)phi;
+  float sX, cX;
+  ptmath::sincosf32(X, &sX, &cX);
+  const double c1 = ptmath::cos64(Y1);
+  const double s2 = ptmath::sin64(Y2);
+  const float x = spec ? (float)((double)sX * c1) : sX * (float)c1;
+  const float z = spec ? (float)((double)sX * s2) : sX * (float)s2;
+  const float y = cX;
+  f3 tangent, bitangent;
+  local_frame(f, tangent, bitangent);
+  const f3 pert = normalize(add(add(scl(tangent, x), scl(f, y)), scl(bitangent, z)));
+  const bool perturb = !spec || bo.roughness > 0.0f;  // a perfect mirror keeps the reflected direction
   s.o = add(hp, scl(hn, 0.001f));
-  s.d = ndir;
+  s.d = perturb ? pert : refl;
 }
 
 // Retirement + wave-level compaction shared by k_shade and k_primary.
