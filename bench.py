@@ -76,6 +76,7 @@ def main() -> None:
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--legacy-traversal", action="store_true", help="A/B: per-lane BVH walk kernel")
     ap.add_argument("--unfused-primary", action="store_true", help="A/B: depth 0 as separate generate/intersect/shade launches")
+    ap.add_argument("--unfused-bounces", action="store_true", help="A/B: depths >= 1 as separate intersect + shade launches")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling only (wrong results): 1 = intersect skips tracing")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket intersect launches with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and psnr (N=1 extras)")
@@ -113,7 +114,7 @@ def main() -> None:
                              iters_per_batch=args.iters_per_batch, num_queues=args.queues,
                              blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels,
                              legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags,
-                             unfused_primary=args.unfused_primary)
+                             unfused_primary=args.unfused_primary, unfused_bounces=args.unfused_bounces)
 
     def barrier():
         if world > 1:
@@ -149,18 +150,35 @@ def main() -> None:
         pass
     roofline = None
     if st.intersect_launches > 0 and isect_s > 0:
-        achieved = ISECT_BYTES_PER_RAY * timed.sum() / isect_s / 1e9
+        nxt = np.append(live[1:], 0.0)  # survivors of depth d = live rays of depth d+1 (none after the last depth)
+        if st.bounces_fused:
+            # fused bounce kernel, depths >= 1: 40 B path state read per ray; written: 40 B per survivor or
+            # 12 B per retired sample (the hit record of SURVEY §8d's 56 + 104 B never reaches HBM)
+            kernel = "k_bounce (computeIntersections + shadeAndExtendRays + compaction, depths 1..7)"
+            alg_bytes = float((40 * live[1:] + 40 * nxt[1:] + 12 * (live[1:] - nxt[1:])).sum())
+            units = float(live[1:].sum())
+            per_unit = "40 B read + 40 B (survivor) / 12 B (retired) written per ray"
+        else:
+            kernel = "k_intersect (computeIntersections)"
+            alg_bytes = float(ISECT_BYTES_PER_RAY * timed.sum())
+            units = float(timed.sum())
+            per_unit = "56 B per live ray (24 read + 32 written)"
+        achieved = alg_bytes / isect_s / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "intersect_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("kernel", "").split(" ")[0] == kernel.split(" ")[0]:
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "k_intersect (computeIntersections)", "achieved": round(achieved, 2),
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "launches": int(st.intersect_launches), "avg_launch_us": round(isect_s * 1e6 / st.intersect_launches, 3),
-                    "algorithmic_bytes_per_launch": round(ISECT_BYTES_PER_RAY * timed.sum() / st.intersect_launches, 1),
+                    "algorithmic_bytes_per_launch": round(alg_bytes / st.intersect_launches, 1),
+                    "algorithmic_bytes_per_unit": per_unit,
+                    "rays_per_launch": round(units / st.intersect_launches, 1),
                     "depths_timed": "1..7 (depth 0 runs in the fused primary kernel)" if st.primary_fused else "0..7",
                     "live_rays_per_sample": round(float(live.sum()) / max(1, st.samples), 4)}
 

@@ -48,14 +48,14 @@ class PtSceneDesc(C.Structure):
 class PtOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("pixel_begin", C.c_int32), ("pixel_count", C.c_int32),
                 ("iters_per_batch", C.c_int32), ("num_queues", C.c_int32), ("blocks_per_cu", C.c_int32),
-                ("time_kernels", C.c_int32), ("legacy_traversal", C.c_int32), ("debug_flags", C.c_int32), ("unfused_primary", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("time_kernels", C.c_int32), ("legacy_traversal", C.c_int32), ("debug_flags", C.c_int32), ("unfused_primary", C.c_int32), ("unfused_bounces", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class PtStats(C.Structure):
     _fields_ = [("samples", C.c_int64), ("live_rays", C.c_int64 * PT_MAX_DEPTH), ("intersect_launches", C.c_int64),
                 ("intersect_ms", C.c_double), ("render_ms", C.c_double), ("num_cus", C.c_int32),
                 ("grid_blocks", C.c_int32), ("num_queues", C.c_int32), ("iters_per_batch", C.c_int32),
-                ("device_bytes", C.c_int64), ("primary_fused", C.c_int32), ("reserved", C.c_int32)]
+                ("device_bytes", C.c_int64), ("primary_fused", C.c_int32), ("bounces_fused", C.c_int32)]
 
 
 class PtError(RuntimeError):
@@ -178,7 +178,8 @@ class Renderer:
 
     def __init__(self, scene: Scene, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
                  iters_per_batch: int = 0, num_queues: int = 0, blocks_per_cu: int = 0, time_kernels: bool = False,
-                 legacy_traversal: bool = False, debug_flags: int = 0, unfused_primary: bool = False):
+                 legacy_traversal: bool = False, debug_flags: int = 0, unfused_primary: bool = False,
+                 unfused_bounces: bool = False):
         opt = PtOptions()
         opt.device = device
         opt.pixel_begin = pixel_begin
@@ -190,6 +191,7 @@ class Renderer:
         opt.legacy_traversal = 1 if legacy_traversal else 0
         opt.debug_flags = int(debug_flags)
         opt.unfused_primary = 1 if unfused_primary else 0
+        opt.unfused_bounces = 1 if unfused_bounces else 0
         self.scene = scene
         w, h = scene.resolution
         self.n = pixel_count if pixel_count > 0 else w * h - pixel_begin

@@ -69,8 +69,8 @@ struct Ctx {
   int num_nodes = 0, num_top = 0;
   bool legacy = false;
   int debug_flags = 0;
-  bool fuse_primary = true;
-  int grid_primary = 0;
+  bool fuse_primary = true, fuse_bounces = true;
+  int grid_primary = 0, grid_bounce = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
   float* d_final = nullptr;
@@ -239,17 +239,23 @@ int run_batch(int iter_first, int kb) {
     const int32_t* cin = g.d_cnt + per_depth * d;
     int32_t* cout = g.d_cnt + per_depth * (d + 1);
     EventPair ev{};
-    if (g.time_kernels) {
+    if (g.time_kernels) {  // brackets the dominant kernel of this depth
       if (get_events(&ev)) return -1;
       HIP_OK(hipEventRecord(ev.a, g.stream));
     }
-    ptk::launch_intersect(g.stream, g.grid_isect, sc, queues_for(g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy);
+    if (g.fuse_bounces) {
+      ptk::launch_bounce(g.stream, g.grid_bounce, sc, b, d, queues_for(g.grid_bounce), cin, cout, g.buf[d & 1],
+                         g.buf[(d + 1) & 1], g.d_final);
+    } else {
+      ptk::launch_intersect(g.stream, g.grid_isect, sc, queues_for(g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy);
+    }
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
       g.pending_isect.push_back(ev);
     }
-    ptk::launch_shade(g.stream, g.grid_shade, sc, b, d, queues_for(g.grid_shade), cin, cout, g.buf[d & 1], g.hits,
-                      g.buf[(d + 1) & 1], g.d_final);
+    if (!g.fuse_bounces)
+      ptk::launch_shade(g.stream, g.grid_shade, sc, b, d, queues_for(g.grid_shade), cin, cout, g.buf[d & 1], g.hits,
+                        g.buf[(d + 1) & 1], g.d_final);
   }
   ptk::launch_count_stats(g.stream, g.qs, g.d_cnt, g.depth, g.d_stats);
   ptk::launch_gather(g.stream, b, g.d_final, g.d_image);
@@ -433,6 +439,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   g.legacy = opt.legacy_traversal != 0;
   g.debug_flags = opt.debug_flags;
   g.fuse_primary = !g.legacy && !opt.unfused_primary;
+  g.fuse_bounces = g.fuse_primary && !opt.unfused_bounces;
   std::vector<ptd::Geom> dg(g.geoms.size());
   for (size_t i = 0; i < g.geoms.size(); ++i) {
     std::memset(&dg[i], 0, sizeof(ptd::Geom));
@@ -467,6 +474,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
     g.grid_isect = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
     g.grid_shade = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kShade, t));
     g.grid_primary = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kPrimary, t));
+    g.grid_bounce = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kBounce, t));
   }
   // path state
   if (alloc_pathbuf(&g.buf[0], g.stride) || alloc_pathbuf(&g.buf[1], g.stride) || alloc_hitbuf(&g.hits, g.stride)) return -1;
@@ -560,6 +568,7 @@ int pt_get_stats(PtStats* out) {
   out->iters_per_batch = g.K;
   out->device_bytes = g.device_bytes;
   out->primary_fused = g.fuse_primary ? 1 : 0;
+  out->bounces_fused = g.fuse_bounces ? 1 : 0;
   return 0;
 }
 

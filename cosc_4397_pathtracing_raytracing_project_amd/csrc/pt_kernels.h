@@ -40,6 +40,9 @@ void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const Batc
 // queues), retired samples to final_rgb; cnt0 receives the per-queue sample counts (statistics only).
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                     const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float* final_rgb);
+// Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.
+void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
+                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float* final_rgb);
 // computeIntersections over the live paths of every queue.
 void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
                       ptd::PathBuf paths, ptd::HitBuf hits, bool legacy = false);
@@ -58,7 +61,7 @@ void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb
 // Resident workgroups per CU for each persistent kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor),
 // so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
 // a workgroup that has to wait for a free slot would run its whole share after everybody else.
-enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4 };
+enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kBounce = 5 };
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc);
 
 // Stage helper for tests: one shading step on n explicit paths (single queue, no compaction):

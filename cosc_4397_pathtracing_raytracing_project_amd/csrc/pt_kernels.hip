@@ -843,6 +843,107 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
   }
 }
 
+// ── depth >= 1 fused: computeIntersections + shadeAndExtendRays + compaction ───────────────
+// Same pipeline as k_primary, but the ray comes from the previous depth's queues.  The hit record
+// never leaves the CU (LDS + registers), which removes its 32-B write and 32-B read per ray and the
+// re-read of the path state by a separate shading kernel: 40 B read + 40 B (survivor) or 12 B
+// (retired) written per ray, against 56 + 100 B for the two-kernel form.  The unfused k_shade is
+// HBM-bound (5.1 TB/s measured) while k_intersect is VALU-bound, so fusing lets the shading traffic
+// overlap the search instead of following it.
+template <bool TABLES_IN_LDS>
+__global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
+                                                   const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
+                                                   ptd::PathBuf in, ptd::PathBuf out, float* __restrict__ final_rgb) {
+  extern __shared__ float4 lds_raw[];
+  char* lds = reinterpret_cast<char*>(lds_raw);
+  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
+  stage16(lds, sc.top, nb_top);
+  stage16(lds + nb_top, sc.mats, nb_mats);
+  const float4* top = reinterpret_cast<const float4*>(lds);
+  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
+  const ptd::Node* nodes = sc.nodes;
+  const ptd::Geom* geoms = sc.geoms;
+  int tbl = nb_top + nb_mats;
+  if (TABLES_IN_LDS) {
+    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
+    stage16(lds + tbl, sc.nodes, nb_nodes);
+    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
+    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
+    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
+    tbl += nb_nodes + nb_geoms;
+  }
+  __syncthreads();
+  const int wib = threadIdx.x >> 6;
+  WaveLds w;
+  {
+    char* base = lds + tbl + wib * kWaveLds;
+    w.best = reinterpret_cast<unsigned long long*>(base);
+    w.rec = reinterpret_cast<float*>(base + 64 * 8);
+    w.list = reinterpret_cast<uint32_t*>(base + 64 * 8 + 7 * 64 * 4);
+  }
+  const int ntop = sc.num_top;
+  const int wave = blockIdx.x * kWavesPerBlock + wib;
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
+  const int64_t S = in.stride;
+  const int64_t FS = (int64_t)b.K * b.N;
+  const int64_t qbase = (int64_t)q * qs.cap;
+  const float inv_n = 1.0f / (float)b.N;
+  struct In {
+    f3 o, d, c;
+    int slot;
+  };
+  const int last = qs.cap - 64 + lane;  // branch-free loads, clamped into the queue's own region
+  auto load = [&](int i) {
+    In v;
+    const int64_t at = qbase + min(i, last);
+    v.o = mk(in.o[at], in.o[S + at], in.o[2 * S + at]);
+    v.d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
+    v.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
+    v.slot = in.slot[at];
+    return v;
+  };
+  In nx = load(r * 64 + lane);
+  for (int j = r; j * 64 < n_q; j += wq) {
+    const int i = j * 64 + lane;
+    const bool valid = i < n_q;
+    const In cur = nx;
+    nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is traced and shaded
+    trace_group(w, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane);
+    const unsigned long long best = w.best[lane];
+    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+    ShadeIO s;
+    s.o = cur.o;
+    s.d = cur.d;
+    s.c = cur.c;
+    s.alive = false;
+    const int slot = cur.slot;
+    Bounce bo;
+    bo.kind = 0;
+    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+    if (valid) {
+      float ht = -1.0f;
+      int hmat = 0;
+      if (hit) {
+        ht = __uint_as_float((uint32_t)(best >> 32));
+        hmat = geoms[nodes[(uint32_t)best].geom].material;
+        hn = mk(w.rec[0 * 64 + lane], w.rec[1 * 64 + lane], w.rec[2 * 64 + lane]);
+        hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
+      }
+      int k, p;
+      divmod(slot, b.N, inv_n, k, p);
+      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, ht, hmat, s);
+    }
+    const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    const bool alive = valid && s.alive;
+    if (alive) shade_bounce(bo, hn, hp, s);
+    emit_survivors(res, alive, s, slot, qbase, out);
+  }
+}
+
 // test-only stage: explicit (iter, pixel) per path, in-place, no compaction
 __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trace_depth, int depth, int n,
                                                         const int32_t* __restrict__ iter,
@@ -946,6 +1047,10 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, primary_lds_bytes(sc, true));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, primary_lds_bytes(sc, false));
       break;
+    case kBounce:
+      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, primary_lds_bytes(sc, true));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, primary_lds_bytes(sc, false));
+      break;
     case kShade:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)));
       break;
@@ -984,6 +1089,14 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
   const bool in_lds = bytes <= kLdsTableBytes;
   if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, false), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
+}
+
+void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
+                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float* final_rgb) {
+  const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
+  const bool in_lds = bytes <= kLdsTableBytes;
+  if (in_lds) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, true), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
+  else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, false), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
 }
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,

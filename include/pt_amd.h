@@ -92,7 +92,9 @@ typedef struct PtOptions {
                                floor of the kernel), bit1 shade skips shading (every path retires) */
   int32_t unfused_primary;  /* 1: run depth 0 as generate + intersect + shade launches instead of the fused
                                primary kernel (A/B and stage-parity runs) */
-  int32_t reserved[6];
+  int32_t unfused_bounces;  /* 1: depths >= 1 as separate computeIntersections + shade launches (hit records
+                               through HBM) instead of the fused bounce kernel (A/B and stage-parity runs) */
+  int32_t reserved[5];
 } PtOptions;
 
 #define PT_MAX_DEPTH 64
@@ -106,7 +108,8 @@ typedef struct PtStats {
   int64_t device_bytes;               /* device memory held by the renderer              */
   int32_t primary_fused;              /* 1: depth 0 ran in the fused primary kernel, so the timed
                                          computeIntersections launches cover depths >= 1 only   */
-  int32_t reserved;
+  int32_t bounces_fused;              /* 1: depths >= 1 ran in the fused bounce kernel; the timed launches
+                                         (intersect_ms / intersect_launches) are then those kernels      */
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,
