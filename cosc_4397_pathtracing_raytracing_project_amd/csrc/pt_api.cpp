@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -170,6 +171,21 @@ void build_top(const std::vector<PtBVHNode>& ref, const std::vector<ptd::Node>& 
     e.idx = where[ref_idx];
     e.link = n.left < 0 ? -1 - geoms[n.geomIndex].type : thr[where[ref_idx]].skip;
     top.push_back(e);
+  }
+}
+
+// normalize(vec3(invTranspose * vec4(n, 0))) in GLM operation order (same expressions as mulMV /
+// normalize in pt_kernels.hip; this file is compiled with -ffp-contract=off, sqrtf and / are IEEE on
+// the host as on the device), for the 7 object-space normals a cube test can produce.
+void box_normal_table(const float invT12[12], float out[7][4]) {
+  for (int code = 0; code < 7; ++code) {
+    float n[3] = {0.f, 0.f, 0.f};
+    if (code > 0) n[(code - 1) / 2] = ((code - 1) & 1) ? 1.0f : -1.0f;
+    const float* m = invT12;
+    float v[3];
+    for (int r = 0; r < 3; ++r) v[r] = (m[0 + r] * n[0] + m[3 + r] * n[1]) + (m[6 + r] * n[2] + m[9 + r] * 0.0f);
+    const float inv = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    out[code][0] = v[0] * inv, out[code][1] = v[1] * inv, out[code][2] = v[2] * inv, out[code][3] = 0.f;
   }
 }
 
@@ -448,6 +464,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
     pack_rows(g.geoms[i].invTranspose, dg[i].invT);
     dg[i].type = g.geoms[i].type;
     dg[i].material = g.geoms[i].materialid;
+    box_normal_table(dg[i].invT, dg[i].box_normal);
   }
   std::vector<ptd::Mat> dm(g.mats.size());
   for (size_t i = 0; i < g.mats.size(); ++i) {

@@ -38,7 +38,7 @@ struct TopEntry {
 };
 static_assert(sizeof(TopEntry) == 32, "TopEntry must be 32 B");
 
-// Geometry record, 160 B.  Only rows 0..2 of each matrix are ever used
+// Geometry record, 272 B.  Only rows 0..2 of each matrix are ever used
 // (multiplyMV returns vec3, src/intersections.h:34-36), stored m[c*3+r] == glm m[c][r].
 struct Geom {
   float inv[12];   // inverseTransform
@@ -47,8 +47,14 @@ struct Geom {
   int32_t type;    // 0 sphere, 1 cube (sceneStructs.h:10-13)
   int32_t material;
   int32_t pad[2];
+  // Cube only: the world-space normal for each of the 7 values the object-space normal of
+  // boxIntersectionTest can take (zero vector, -x, +x, -y, +y, -z, +z), i.e.
+  // normalize(vec3(invTranspose * vec4(n, 0))) (intersections.h:86) evaluated on the host with the
+  // same float operations in the same order — the kernel looks the result up instead of redoing a
+  // mat*vec, a dot, a sqrt and a divide per candidate.  [code][xyz, pad]
+  float box_normal[7][4];
 };
-static_assert(sizeof(Geom) == 160, "Geom must be 160 B");
+static_assert(sizeof(Geom) == 272, "Geom must be 272 B");
 
 // The five Material fields shading reads (sceneStructs.h:38-48), 48 B.
 struct Mat {

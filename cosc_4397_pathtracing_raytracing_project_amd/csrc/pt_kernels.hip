@@ -178,9 +178,10 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
   float t;
   f3 nobj = mk(0.f, 0.f, 0.f);
   bool flip = false;
+  int ncode = 0;  // cube: which of the 7 possible object-space normals (0 = zero vector, 1 + 2*axis + (sign > 0))
   if (is_box) {
     float tmin = -1e38f, tmax = 1e38f;
-    f3 tmin_n = mk(0.f, 0.f, 0.f), tmax_n = mk(0.f, 0.f, 0.f);
+    int tmin_c = 0, tmax_c = 0;
     const float qdv[3] = {qd.x, qd.y, qd.z};
     const float qov[3] = {qo.x, qo.y, qo.z};
 #pragma unroll
@@ -189,24 +190,23 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
       const float t2 = (+0.5f - qov[a]) / qdv[a];
       const float ta = t1 < t2 ? t1 : t2;  // glm::min
       const float tb = t1 > t2 ? t1 : t2;  // glm::max
-      const float s = t2 < t1 ? 1.0f : -1.0f;
-      const f3 n = mk(a == 0 ? s : 0.f, a == 1 ? s : 0.f, a == 2 ? s : 0.f);
+      const int c = 1 + 2 * a + (t2 < t1 ? 1 : 0);  // n[xyz] = t2 < t1 ? +1 : -1
       if (ta > 0.f && ta > tmin) {
         tmin = ta;
-        tmin_n = n;
+        tmin_c = c;
       }
       if (tb < tmax) {
         tmax = tb;
-        tmax_n = n;
+        tmax_c = c;
       }
     }
     if (!(tmax >= tmin && tmax > 0.f)) return -1.0f;
     if (tmin <= 0.f) {
       tmin = tmax;
-      tmin_n = tmax_n;
+      tmin_c = tmax_c;
     }
     t = tmin;
-    nobj = tmin_n;
+    ncode = tmin_c;
   } else {
     // radius .5 → powf(.5, 2) = .25
     const float vDotDirection = dot(qo, qd);
@@ -228,8 +228,12 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
   const f3 objp = add(qo, scl(normalize(qd), t - .0001f));
   if (!is_box) nobj = objp;
   point = mulMV(G->xf, objp, 1.0f);
-  normal = normalize(mulMV(G->invT, nobj, 0.0f));
-  if (flip) normal = neg(normal);
+  if (is_box) {
+    normal = mk(G->box_normal[ncode][0], G->box_normal[ncode][1], G->box_normal[ncode][2]);  // precomputed, exact
+  } else {
+    normal = normalize(mulMV(G->invT, nobj, 0.0f));
+    if (flip) normal = neg(normal);
+  }
   return length(sub(ro_w, point));
 }
 

@@ -32,6 +32,8 @@ def scene_dir(tmp_path_factory):
         "cornell": scenes.write_scene(scenes.cornell_scene_text(), str(d / "cornell.txt")),
         "sphere": scenes.write_scene(scenes.sphere_scene_text(), str(d / "sphere.txt")),
         "stress": scenes.write_scene(scenes.stress_scene_text((6, 5, 4), res=(160, 90)), str(d / "stress.txt")),
+        # > 64 KB of BVH + geometry tables: exercises the kernels' global-memory table path and real subtrees
+        "stress_big": scenes.write_scene(scenes.stress_scene_text((10, 10, 8), res=(160, 90)), str(d / "stress_big.txt")),
     }
     return paths
 

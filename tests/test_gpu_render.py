@@ -51,6 +51,9 @@ def gpu_render(scene_path, res, spp, depth=None, first=1, **kw):
     ("cornell", (200, 120), 7, 8, dict(unfused_primary=True, iters_per_batch=2)),
     ("cornell", (200, 120), 7, 8, dict(unfused_bounces=True, iters_per_batch=4)),
     ("stress", (160, 90), 6, 8, dict(unfused_bounces=True)),
+    ("stress_big", (160, 90), 4, 8, {}),
+    ("stress_big", (128, 72), 3, 8, dict(unfused_primary=True)),
+    ("stress_big", (128, 72), 3, 8, dict(legacy_traversal=True)),
     ("stress", (160, 90), 6, 8, dict(unfused_primary=True)),
     ("sphere", (256, 256), 16, 4, dict(unfused_primary=True)),
 ])

@@ -45,7 +45,7 @@ def test_generate(gpu, oracle, scene, res):
         assert np.array_equal(bits(go), bits(oo)) and np.array_equal(bits(gd), bits(od))
 
 
-@pytest.mark.parametrize("scene,res", [("cornell", (640, 360)), ("sphere", (200, 200)), ("stress", (320, 180))])
+@pytest.mark.parametrize("scene,res", [("cornell", (640, 360)), ("sphere", (200, 200)), ("stress", (320, 180)), ("stress_big", (320, 180))])
 def test_intersect_primary_rays(gpu, oracle, scene, res):
     R, sc = gpu(scene, res=res)
     o, d = oracle.generate(0, res[0] * res[1])

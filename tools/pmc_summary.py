@@ -15,7 +15,7 @@ def load(d):
     return out
 
 def short(n):
-    for k in ("k_intersect_legacy", "k_intersect", "k_shade", "k_generate", "k_gather", "k_count_stats"):
+    for k in ("k_intersect_legacy", "k_intersect", "k_shade", "k_generate", "k_primary", "k_bounce", "k_gather", "k_count_stats"):
         if k in n:
             return k
     return None
@@ -29,13 +29,13 @@ def main():
     for (p, did), v in sorted(data.items()):
         bypass[p].append((did, v))
     for p, lst in bypass.items():
-        depth = {"k_intersect": 0, "k_shade": 0, "k_intersect_legacy": 0}
+        depth = {"k_intersect": 0, "k_shade": 0, "k_intersect_legacy": 0, "k_bounce": 1}
         for did, v in lst:
             s = short(v["name"])
             if s is None:
                 continue
-            if s == "k_generate":
-                depth = {k: 0 for k in depth}
+            if s in ("k_generate", "k_primary"):
+                depth = {k: (1 if k == "k_bounce" else 0) for k in depth}
             tag = s
             if s in depth:
                 tag = f"{s}[d{depth[s]}]"

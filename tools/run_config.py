@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Render one BASELINE configuration through the C ABI, report Msamples/s and check rows against the oracle.
+usage: tools/run_config.py {cornell|sphere|stress} --res WxH --spp N [--depth D] [--grid X,Y,Z] [--check-rows R1,R2] [--save PREFIX]"""
+import argparse, os, sys, tempfile, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cosc_4397_pathtracing_raytracing_project_amd import capi, scenes
+
+ap = argparse.ArgumentParser()
+ap.add_argument("scene")
+ap.add_argument("--res", default="1920x1080")
+ap.add_argument("--spp", type=int, default=100)
+ap.add_argument("--depth", type=int, default=8)
+ap.add_argument("--grid", default="22,22,21")
+ap.add_argument("--check-rows", default="")
+ap.add_argument("--save", default="")
+ap.add_argument("--iters-per-batch", type=int, default=0)
+a = ap.parse_args()
+w, h = map(int, a.res.split("x"))
+txt = {"cornell": scenes.cornell_scene_text, "sphere": scenes.sphere_scene_text}.get(a.scene)
+text = txt(res=(w, h), depth=a.depth) if txt else scenes.stress_scene_text(tuple(map(int, a.grid.split(","))), res=(w, h), depth=a.depth)
+path = scenes.write_scene(text, os.path.join(tempfile.mkdtemp(), a.scene + ".txt"))
+sc = capi.Scene(path, res=(w, h))
+print(f"{a.scene}: {sc.desc.num_geoms} geoms, {len(sc.bvh())} BVH nodes, {w}x{h}, depth {sc.trace_depth}")
+r = capi.Renderer(sc, iters_per_batch=a.iters_per_batch, time_kernels=True)
+r.render(1, max(2, a.spp // 10)); r.sync(); r.free()
+r = capi.Renderer(sc, iters_per_batch=a.iters_per_batch, time_kernels=True)
+t0 = time.perf_counter(); r.render(1, a.spp); img = r.readback(); dt = time.perf_counter() - t0
+st = r.stats(); r.free()
+live = np.array(st.live_rays[:a.depth], float)
+print(f"{a.spp} spp in {dt:.3f} s = {w*h*a.spp/dt/1e6:.1f} Msamples/s; live rays/sample {live.sum()/st.samples:.3f}; "
+      f"alive by depth {np.round(live/st.samples, 4).tolist()}; dominant kernel {st.intersect_ms/max(1,st.intersect_launches)*1e3:.1f} us x {st.intersect_launches}; "
+      f"K={st.iters_per_batch}, device mem {st.device_bytes/2**20:.0f} MB")
+print("mean RGB", (img / np.float32(a.spp)).mean(axis=0, dtype=np.float64), "finite", bool(np.isfinite(img).all()))
+if a.check_rows:
+    from oracle import binding as ob
+    ob.set_math_mode(ob.PORTABLE); ob.load_scene(path, res=(w, h))
+    for row in map(int, a.check_rows.split(",")):
+        ref = ob.render(1, a.spp, depth=a.depth, variant=ob.RETIRE, nthreads=min(32, os.cpu_count()), pix_begin=row * w, pix_count=w)
+        print(f"row {row}: bit-exact vs oracle = {np.array_equal(img[row*w:(row+1)*w].view(np.uint32), ref.view(np.uint32))}")
+if a.save:
+    capi.save_png(a.save + ".png", img, w, h, float(a.spp))
