@@ -367,24 +367,20 @@ PT_DEV float bperm(int src_lane, float v) {
 }
 
 // Runs the pending candidates; called at wave-uniform control flow with all 64 lanes active.
-PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
-                             const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
-  const int total = nb + ns;
-  for (int base = 0; base < total; base += 64) {
+template <int TYPE>
+PT_DEV void flush_type(const WaveLds& w, int first, int count, int lane, f3 o, f3 d,
+                       const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+  for (int base = 0; base < count; base += 64) {
     const int e = base + lane;
-    const bool valid = e < total;
-    const bool is_box = e < nb;
-    const uint32_t entry = valid ? w.list[is_box ? e : kCandCap - total + e] : (uint32_t)lane;
+    const bool valid = e < count;
+    const uint32_t entry = valid ? w.list[first + e] : (uint32_t)lane;
     const int src = (int)(entry & 63u);
     const uint32_t leaf = entry >> 6;
     const f3 ro = mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
     const f3 rd = mk(bperm(src, d.x), bperm(src, d.y), bperm(src, d.z));
     const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
     f3 pt, nrm;
-    float t;
-    if (base + 64 <= nb) t = geom_test<1>(G, ro, rd, pt, nrm);       // chunk of cubes only
-    else if (base >= nb) t = geom_test<0>(G, ro, rd, pt, nrm);      // chunk of spheres only
-    else t = is_box ? geom_test<1>(G, ro, rd, pt, nrm) : geom_test<0>(G, ro, rd, pt, nrm);
+    const float t = geom_test<TYPE>(G, ro, rd, pt, nrm);
     const uint32_t tb = __float_as_uint(t);
     if (valid && t > 0.f && tb < 0x7f7fffffu) {
       const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
@@ -395,6 +391,13 @@ PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f
       }
     }
   }
+}
+// Cubes and spheres are run as separate chunk sequences: a chunk holding both kinds would execute both
+// code paths for all 64 lanes (typical group at depth >= 1: ~55 cubes + ~12 spheres).
+PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
+                             const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+  flush_type<1>(w, 0, nb, lane, o, d, nodes, geoms);
+  flush_type<0>(w, kCandCap - ns, ns, lane, o, d, nodes, geoms);
 }
 
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
