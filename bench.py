@@ -76,6 +76,7 @@ def main() -> None:
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--legacy-traversal", action="store_true", help="A/B: per-lane BVH walk kernel")
     ap.add_argument("--unfused-primary", action="store_true", help="A/B: depth 0 as separate generate/intersect/shade launches")
+    ap.add_argument("--contiguous-tiles", action="store_true", help="A/B: one block of rows per rank instead of interleaved rows")
     ap.add_argument("--unfused-bounces", action="store_true", help="A/B: depths >= 1 as separate intersect + shade launches")
     ap.add_argument("--debug-flags", type=int, default=0, help="profiling only (wrong results): 1 = intersect skips tracing")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket intersect launches with HIP events")
@@ -97,20 +98,36 @@ def main() -> None:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal on a 1-GPU box: PT_DIST_BACKEND=gloo lets several ranks share one card (RCCL needs one GPU per
+    # rank); the tiles are then gathered through host memory.  The driver's runs use the default, nccl.
+    backend = os.environ.get("PT_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible")
+    local_rank = local_rank % max(1, ndev)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     tmp = tempfile.mkdtemp(prefix="ptbench_")
     scene_path = scenes.write_scene(scenes.cornell_scene_text(res=(W, H), iterations=args.steps, depth=DEPTH),
                                     os.path.join(tmp, f"cornell_{rank}.txt"))
     scene = capi.Scene(scene_path, res=(W, H))
-    begin, count = parallel.tile_for_rank(W, H, rank, world)
+    striped = world > 1 and not args.contiguous_tiles
+    if striped:
+        topt = parallel.striped_tile_for_rank(W, H, rank, world)
+    else:
+        begin, count = parallel.tile_for_rank(W, H, rank, world)
+        topt = dict(pixel_begin=begin, pixel_count=count)
+    count = topt["pixel_count"]
     tile = torch.zeros((count, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def make_renderer(time_kernels: bool):
-        return capi.Renderer(scene, device=local_rank, pixel_begin=begin, pixel_count=count,
+        return capi.Renderer(scene, device=local_rank, **topt,
                              iters_per_batch=args.iters_per_batch, num_queues=args.queues,
                              blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels,
                              legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags,
@@ -126,7 +143,7 @@ def main() -> None:
     if args.warmup > 0:
         r.render(1, args.warmup)
         r.readback_device(tile.data_ptr())
-        parallel.gather_tiles(tile, W, H, rank, world)
+        parallel.gather_tiles(tile, W, H, rank, world, striped=striped)
     r.free()
     r = make_renderer(not args.no_kernel_events)
 
@@ -134,11 +151,11 @@ def main() -> None:
     t0 = time.perf_counter()
     r.render(1, args.steps)                 # K steps: all launches are asynchronous on the render stream
     r.readback_device(tile.data_ptr())      # waits for the stream, tile SUM image → torch tensor
-    full = parallel.gather_tiles(tile, W, H, rank, world)  # single RCCL gather at image write-out
+    full = parallel.gather_tiles(tile, W, H, rank, world, striped=striped)  # single RCCL gather at image write-out
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -197,7 +214,7 @@ def main() -> None:
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"cornell.txt 1920x1080, {args.steps} spp, depth 8, BVH + compaction, "
-                               f"{world}x MI355X row tiles" + (", one RCCL gather" if world > 1 else ""),
+                               f"{world}x MI355X " + ("interleaved-row tiles" if striped else "row tiles") + (", one RCCL gather" if world > 1 else ""),
                    "iters_per_batch": int(st.iters_per_batch), "queues": int(st.num_queues),
                    "grid_blocks": int(st.grid_blocks), "cus": int(st.num_cus),
                    "device_mem_mb": round(st.device_bytes / 2 ** 20, 1),

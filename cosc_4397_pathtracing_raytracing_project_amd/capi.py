@@ -48,7 +48,8 @@ class PtSceneDesc(C.Structure):
 class PtOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("pixel_begin", C.c_int32), ("pixel_count", C.c_int32),
                 ("iters_per_batch", C.c_int32), ("num_queues", C.c_int32), ("blocks_per_cu", C.c_int32),
-                ("time_kernels", C.c_int32), ("legacy_traversal", C.c_int32), ("debug_flags", C.c_int32), ("unfused_primary", C.c_int32), ("unfused_bounces", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("time_kernels", C.c_int32), ("legacy_traversal", C.c_int32), ("debug_flags", C.c_int32), ("unfused_primary", C.c_int32), ("unfused_bounces", C.c_int32), ("stripe_pixels", C.c_int32), ("stripe_stride", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class PtStats(C.Structure):
@@ -179,7 +180,7 @@ class Renderer:
     def __init__(self, scene: Scene, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
                  iters_per_batch: int = 0, num_queues: int = 0, blocks_per_cu: int = 0, time_kernels: bool = False,
                  legacy_traversal: bool = False, debug_flags: int = 0, unfused_primary: bool = False,
-                 unfused_bounces: bool = False):
+                 unfused_bounces: bool = False, stripe_pixels: int = 0, stripe_stride: int = 0):
         opt = PtOptions()
         opt.device = device
         opt.pixel_begin = pixel_begin
@@ -192,6 +193,8 @@ class Renderer:
         opt.debug_flags = int(debug_flags)
         opt.unfused_primary = 1 if unfused_primary else 0
         opt.unfused_bounces = 1 if unfused_bounces else 0
+        opt.stripe_pixels = int(stripe_pixels)
+        opt.stripe_stride = int(stripe_stride)
         self.scene = scene
         w, h = scene.resolution
         self.n = pixel_count if pixel_count > 0 else w * h - pixel_begin

@@ -56,6 +56,7 @@ struct Ctx {
   int depth = 0;
   // tile / batch geometry
   int N = 0, pixel_begin = 0, K = 1;
+  int stripe = 0, stripe_stride = 0;
   int num_cus = 0, grid = 0;  // grid: widest persistent grid (stats / test stages)
   int grid_gen = 0, grid_isect = 0, grid_shade = 0;
   ptd::Queues qs{};
@@ -238,6 +239,9 @@ int run_batch(int iter_first, int kb) {
   b.N = g.N;
   b.pixel_begin = g.pixel_begin;
   b.trace_depth = g.depth;
+  b.stripe = g.stripe;
+  b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;
+  b.inv_stripe = g.stripe ? 1.0f / (float)g.stripe : 0.0f;
   const size_t cnt_ints = (size_t)(g.depth + 1) * g.qs.Q * g.qs.cnt_stride;
   HIP_OK(hipMemsetAsync(g.d_cnt, 0, cnt_ints * sizeof(int32_t), g.stream));
   const ptk::SceneTables sc = tables();
@@ -414,15 +418,24 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
 
   g.pixel_begin = opt.pixel_begin;
   g.N = opt.pixel_count > 0 ? opt.pixel_count : W * H - opt.pixel_begin;
-  if (g.pixel_begin < 0 || g.N <= 0 || (int64_t)g.pixel_begin + g.N > (int64_t)W * H)
-    return fail("pt_init: tile [%d, +%d) outside %dx%d", opt.pixel_begin, opt.pixel_count, W, H);
-
+  g.stripe = opt.stripe_pixels;
+  g.stripe_stride = opt.stripe_stride;
+  if (g.stripe < 0 || (g.stripe > 0 && g.stripe_stride < g.stripe)) return fail("pt_init: bad stripe %d / stride %d", g.stripe, g.stripe_stride);
+  {
+    // last global pixel the tile touches
+    int64_t last = (int64_t)g.pixel_begin + g.N - 1;
+    if (g.stripe > 0) last = (int64_t)g.pixel_begin + (g.N - 1) + (int64_t)((g.N - 1) / g.stripe) * (g.stripe_stride - g.stripe);
+    if (g.pixel_begin < 0 || g.N <= 0 || last >= (int64_t)W * H)
+      return fail("pt_init: tile [%d, +%d, stripe %d/%d) outside %dx%d", opt.pixel_begin, opt.pixel_count, g.stripe, g.stripe_stride, W, H);
+    if (g.stripe > 0 && g.N / g.stripe >= 32768) return fail("pt_init: more than 32767 stripes");
+    if (H >= 32768) return fail("pt_init: image height %d not supported (>= 32768)", H);
+  }
   // batch size: enough paths in flight to fill the chip a few times over; slots are int32
   int K = opt.iters_per_batch;
   if (K <= 0) {
     const int64_t target = 48ll << 20;  // ~50 M paths per batch (24 iterations of 1920x1080, ~5 GB of path state):
                                         // launch boundaries drop below 1 % of a batch (measured K=6 → 48: +8 %)
-    K = (int)std::max<int64_t>(1, std::min<int64_t>(64, (target + g.N - 1) / g.N));
+    K = (int)std::max<int64_t>(1, std::min<int64_t>(256, (target + g.N - 1) / g.N));
   }
   while ((int64_t)K * g.N > (1ll << 30) && K > 1) --K;
   g.K = K;

@@ -29,6 +29,10 @@ struct BatchInfo {
   int32_t K;            // iterations in this batch
   int32_t N;            // pixels in the tile
   int32_t pixel_begin;  // global index of tile pixel 0
+  // Striped tiles (multi-GPU load balance): the tile is every `stripe`-pixel run out of `stripe + gap`;
+  // tile pixel p is global pixel pixel_begin + p + (p / stripe) * gap.  stripe == 0: contiguous tile.
+  int32_t stripe, gap;
+  float inv_stripe;
   int32_t trace_depth;
 };
 

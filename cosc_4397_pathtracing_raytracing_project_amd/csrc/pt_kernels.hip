@@ -110,6 +110,14 @@ PT_DEV void stage16(void* lds, const void* g, int bytes) {
   for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) dst[i] = src[i];
 }
 
+// Tile pixel → global pixel index (what keys the RNG and the camera ray), see BatchInfo::stripe.
+PT_DEV int global_pixel(const BatchInfo& b, int p) {
+  if (b.stripe == 0) return b.pixel_begin + p;
+  int i, r;
+  divmod(p, b.stripe, b.inv_stripe, i, r);
+  return b.pixel_begin + p + i * b.gap;
+}
+
 // ───────────────────────────── generate ────────────────────────────────────
 // generateRayFromCamera (pathtrace.cu:270-286) for global pixel index p:
 // dir = normalize(view - right*pl.x*(x - W/2) - up*pl.y*(y - H/2)); no jitter, `iter` unused.
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
     if (gid < total) {
       int k, pl;
       divmod((int)gid, b.N, inv_n, k, pl);
-      const int p = pl + b.pixel_begin;  // global pixel index
+      const int p = global_pixel(b, pl);  // global pixel index
       const f3 d = camera_dir(cam, inv_w, p);
       const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
       out.o[at] = cam.pos[0], out.o[S + at] = cam.pos[1], out.o[2 * S + at] = cam.pos[2];
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     if (valid) {
       int k, p;
       divmod(slot, b.N, inv_n, k, p);
-      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, cur.ht, cur.hmat, s);
+      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, global_pixel(b, p), cur.ht, cur.hmat, s);
     }
     const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     const int slot = (int)(valid ? gid : total - 1);
     int k, pl;
     divmod(slot, b.N, inv_n, k, pl);
-    const int p = pl + b.pixel_begin;  // global pixel index
+    const int p = global_pixel(b, pl);  // global pixel index
     const f3 d = camera_dir(cam, inv_w, p);
     trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
     const unsigned long long best = w.best[lane];
@@ -942,7 +950,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
       }
       int k, p;
       divmod(slot, b.N, inv_n, k, p);
-      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, b.pixel_begin + p, ht, hmat, s);
+      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, global_pixel(b, p), ht, hmat, s);
     }
     const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;

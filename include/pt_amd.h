@@ -94,7 +94,10 @@ typedef struct PtOptions {
                                primary kernel (A/B and stage-parity runs) */
   int32_t unfused_bounces;  /* 1: depths >= 1 as separate computeIntersections + shade launches (hit records
                                through HBM) instead of the fused bounce kernel (A/B and stage-parity runs) */
-  int32_t reserved[5];
+  int32_t stripe_pixels;    /* striped tile for multi-GPU load balance: the tile consists of runs of          */
+  int32_t stripe_stride;    /*   stripe_pixels pixels starting every stripe_stride pixels from pixel_begin;     */
+                            /*   pixel_count counts the tile's own pixels.  0 = one contiguous run              */
+  int32_t reserved[3];
 } PtOptions;
 
 #define PT_MAX_DEPTH 64

@@ -110,6 +110,23 @@ def test_tiles_and_iteration_ranges_compose(scene_dir):
         r.free()
 
 
+def test_striped_tiles_compose(scene_dir):
+    """Row-interleaved tiles (the multi-GPU partition): every rank's rows, scattered back, give the
+    single-shot image bit-for-bit; also with a tile whose last stripe is shorter than the others' count."""
+    from cosc_4397_pathtracing_raytracing_project_amd import parallel
+    res, spp = (96, 50), 5
+    w, h = res
+    full, _ = gpu_render(scene_dir["cornell"], res, spp)
+    for world in (3, 8):
+        out = np.zeros((h, w, 3), np.float32)
+        for rank in range(world):
+            o = parallel.striped_tile_for_rank(w, h, rank, world)
+            img, st = gpu_render(scene_dir["cornell"], res, spp, **o)
+            out[rank::world] = img.reshape(-1, w, 3)
+            assert st.samples == o["pixel_count"] * spp
+        assert np.array_equal(bits(out.reshape(-1, 3)), bits(full))
+
+
 def test_determinism_and_reinit(scene_dir):
     a, _ = gpu_render(scene_dir["cornell"], (128, 128), 4)
     b, _ = gpu_render(scene_dir["cornell"], (128, 128), 4, num_queues=64)

@@ -40,16 +40,40 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, scene_path, res, spp, out_path):
+def test_striped_partition_covers_frame_exactly():
+    for (w, h) in ((1920, 1080), (800, 800), (7, 5)):
+        for world in (1, 2, 3, 8):
+            if world > h:
+                continue
+            seen = np.zeros(w * h, np.int32)
+            for r in range(world):
+                o = parallel.striped_tile_for_rank(w, h, r, world)
+                rows = parallel.striped_rows(h, r, world)
+                assert o["pixel_count"] == len(rows) * w and o["pixel_begin"] == r * w
+                p = np.arange(o["pixel_count"])
+                g = o["pixel_begin"] + p + ((p // o["stripe_pixels"]) * (o["stripe_stride"] - o["stripe_pixels"]) if o["stripe_pixels"] else 0)
+                assert np.array_equal(g // w, np.repeat(rows, w))
+                seen[g] += 1
+            assert (seen == 1).all()
+    o = parallel.striped_tile_for_rank(1920, 1080, 3, 8)
+    assert o == dict(pixel_begin=3 * 1920, pixel_count=135 * 1920, stripe_pixels=1920, stripe_stride=8 * 1920)
+
+
+def _worker(rank, world, port, scene_path, res, spp, out_path, striped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import binding as ob
     ob.set_math_mode(ob.PORTABLE)
     ob.load_scene(scene_path, res=res)
-    begin, count = parallel.tile_for_rank(res[0], res[1], rank, world)
-    tile = torch.from_numpy(ob.render(1, spp, depth=8, variant=ob.RETIRE, pix_begin=begin, pix_count=count))
-    full = parallel.gather_tiles(tile, res[0], res[1], rank, world)
+    if striped:
+        rows = parallel.striped_rows(res[1], rank, world)
+        tile = torch.from_numpy(np.concatenate([ob.render(1, spp, depth=8, variant=ob.RETIRE, pix_begin=y * res[0], pix_count=res[0]) for y in rows]))
+        assert tile.shape[0] == parallel.striped_tile_for_rank(res[0], res[1], rank, world)["pixel_count"]
+    else:
+        begin, count = parallel.tile_for_rank(res[0], res[1], rank, world)
+        tile = torch.from_numpy(ob.render(1, spp, depth=8, variant=ob.RETIRE, pix_begin=begin, pix_count=count))
+    full = parallel.gather_tiles(tile, res[0], res[1], rank, world, striped=striped)
     if rank == 0:
         np.save(out_path, full.numpy())
     else:
@@ -58,11 +82,11 @@ def _worker(rank, world, port, scene_path, res, spp, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_reassembles_single_process_image(scene_dir, tmp_path, world):
+@pytest.mark.parametrize("world,striped", [(2, False), (3, False), (2, True), (3, True)])
+def test_gather_reassembles_single_process_image(scene_dir, tmp_path, world, striped):
     res, spp = (48, 31), 3  # 31 rows: uneven tiles, exercises the padded gather
     out = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(world, _free_port(), scene_dir["cornell"], res, spp, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), scene_dir["cornell"], res, spp, out, striped), nprocs=world, join=True)
     from oracle import binding as ob
     ob.set_math_mode(ob.PORTABLE)
     ob.load_scene(scene_dir["cornell"], res=res)
