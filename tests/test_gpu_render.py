@@ -161,6 +161,49 @@ def test_full_size_properties_1080p(scene_dir, oracle):
         assert np.array_equal(bits(img[row * 1920:(row + 1) * 1920]), bits(ref)), row
 
 
+@pytest.mark.parametrize("res,spp,depth", [((1, 1), 40, 8), ((1, 37), 9, 8), ((301, 1), 5, 3), ((64, 64), 1, 64)])
+def test_degenerate_sizes(scene_dir, oracle, res, spp, depth):
+    """One-pixel / one-column / one-row frames (every queue but one is empty, K hits its cap) and the
+    deepest allowed trace depth (PT_MAX_DEPTH = 64)."""
+    img, st = gpu_render(scene_dir["cornell"], res, spp, depth)
+    oracle.set_math_mode(oracle.PORTABLE)
+    oracle.load_scene(scene_dir["cornell"], res=res)
+    ref = oracle.render(1, spp, depth=depth, variant=oracle.RETIRE, nthreads=4)
+    assert np.array_equal(bits(img), bits(ref))
+    assert st.samples == res[0] * res[1] * spp
+
+
+def test_init_errors(scene_dir):
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    sc = capi.Scene(scene_dir["cornell"], res=(32, 32))
+    for bad in (dict(pixel_begin=1000, pixel_count=100), dict(pixel_begin=-1), dict(device=99),
+                dict(pixel_begin=0, pixel_count=64, stripe_pixels=32, stripe_stride=16),
+                dict(pixel_begin=0, pixel_count=1024, stripe_pixels=32, stripe_stride=64)):
+        with pytest.raises(capi.PtError):
+            capi.Renderer(sc, **bad)
+    sc.trace_depth = 65
+    with pytest.raises(capi.PtError):
+        capi.Renderer(sc)
+    sc.trace_depth = 0
+    with pytest.raises(capi.PtError):
+        capi.Renderer(sc)
+    capi.pt_free()
+
+
+def test_large_frame_4k_properties(scene_dir, oracle):
+    """3840x2160 (8.3 M pixels, 4x the benchmark frame): finite, corners = spp * 0.5^8, two rows bit-exact."""
+    res, spp = (3840, 2160), 2
+    img, st = gpu_render(scene_dir["cornell"], res, spp)
+    n = res[0] * res[1]
+    assert np.isfinite(img).all() and st.samples == n * spp
+    assert np.array_equal(img[[0, res[0] - 1, n - res[0], n - 1], 2], np.full(4, spp * 0.5 ** 8, np.float32))
+    oracle.set_math_mode(oracle.PORTABLE)
+    oracle.load_scene(scene_dir["cornell"], res=res)
+    for row in (1080, 2159):
+        ref = oracle.render(1, spp, depth=8, variant=oracle.RETIRE, nthreads=8, pix_begin=row * res[0], pix_count=res[0])
+        assert np.array_equal(bits(img[row * res[0]:(row + 1) * res[0]]), bits(ref)), row
+
+
 def test_preview_and_png(scene_dir, tmp_path):
     from cosc_4397_pathtracing_raytracing_project_amd import capi
     res, spp = (64, 48), 4
