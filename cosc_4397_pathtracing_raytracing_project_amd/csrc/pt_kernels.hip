@@ -375,37 +375,48 @@ PT_DEV float bperm(int src_lane, float v) {
 }
 
 // Runs the pending candidates; called at wave-uniform control flow with all 64 lanes active.
+// One chunk of <= 64 candidates: `nc` cubes starting at list[cfirst] followed by `nsph` spheres starting at
+// list[sfirst].  TYPE 1 / 0: the chunk holds only cubes / only spheres (specialised code); TYPE -1: both —
+// the object-space transform of the ray and the world-space reconstruction are executed once for all
+// lanes and only the slab / quadratic middle parts diverge (geom_test<-1>).
 template <int TYPE>
-PT_DEV void flush_type(const WaveLds& w, int first, int count, int lane, f3 o, f3 d,
-                       const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
-  for (int base = 0; base < count; base += 64) {
-    const int e = base + lane;
-    const bool valid = e < count;
-    const uint32_t entry = valid ? w.list[first + e] : (uint32_t)lane;
-    const int src = (int)(entry & 63u);
-    const uint32_t leaf = entry >> 6;
-    const f3 ro = mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
-    const f3 rd = mk(bperm(src, d.x), bperm(src, d.y), bperm(src, d.z));
-    const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
-    f3 pt, nrm;
-    const float t = geom_test<TYPE>(G, ro, rd, pt, nrm);
-    const uint32_t tb = __float_as_uint(t);
-    if (valid && t > 0.f && tb < 0x7f7fffffu) {
-      const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
-      atomicMin(&w.best[src], key);
-      if (w.best[src] == key) {  // this candidate is the ray's best so far: publish its record
-        w.rec[0 * 64 + src] = nrm.x, w.rec[1 * 64 + src] = nrm.y, w.rec[2 * 64 + src] = nrm.z;
-        w.rec[3 * 64 + src] = pt.x, w.rec[4 * 64 + src] = pt.y, w.rec[5 * 64 + src] = pt.z;
-      }
+PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph, int lane, f3 o, f3 d,
+                      const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+  const bool valid = lane < nc + nsph;
+  const uint32_t entry = valid ? w.list[lane < nc ? cfirst + lane : sfirst + (lane - nc)] : (uint32_t)lane;
+  const int src = (int)(entry & 63u);
+  const uint32_t leaf = entry >> 6;
+  const f3 ro = mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
+  const f3 rd = mk(bperm(src, d.x), bperm(src, d.y), bperm(src, d.z));
+  const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
+  f3 pt, nrm;
+  const float t = geom_test<TYPE>(G, ro, rd, pt, nrm);
+  const uint32_t tb = __float_as_uint(t);
+  if (valid && t > 0.f && tb < 0x7f7fffffu) {
+    const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
+    atomicMin(&w.best[src], key);
+    if (w.best[src] == key) {  // this candidate is the ray's best so far: publish its record
+      w.rec[0 * 64 + src] = nrm.x, w.rec[1 * 64 + src] = nrm.y, w.rec[2 * 64 + src] = nrm.z;
+      w.rec[3 * 64 + src] = pt.x, w.rec[4 * 64 + src] = pt.y, w.rec[5 * 64 + src] = pt.z;
     }
   }
 }
-// Cubes and spheres are run as separate chunk sequences: a chunk holding both kinds would execute both
-// code paths for all 64 lanes (typical group at depth >= 1: ~55 cubes + ~12 spheres).
+// Runs the pending candidates; called at wave-uniform control flow with all 64 lanes active.
+// Chunk plan (a typical group at depth >= 1 holds ~55 cubes and ~12 spheres): full chunks of cubes,
+// then the remaining cubes together with the spheres in ONE mixed chunk if they fit in 64 lanes
+// (costs ~1.3x a pure chunk instead of two pure chunks), otherwise separately.
 PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
                              const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
-  flush_type<1>(w, 0, nb, lane, o, d, nodes, geoms);
-  flush_type<0>(w, kCandCap - ns, ns, lane, o, d, nodes, geoms);
+  const int sbase = kCandCap - ns;
+  int c0 = 0;
+  for (; c0 + 64 <= nb; c0 += 64) run_chunk<1>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms);
+  const int rem = nb - c0;
+  if (rem > 0 && ns > 0 && rem + ns <= 64) {
+    run_chunk<-1>(w, c0, rem, sbase, ns, lane, o, d, nodes, geoms);
+    return;
+  }
+  if (rem > 0) run_chunk<1>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms);
+  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms);
 }
 
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return

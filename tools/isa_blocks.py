@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "cosc_4397_pathtracing_raytracing_project_amd", "csrc", "pt_kernels.hip")
 out = os.path.join(ROOT, "build", "scratch", "pt_kernels.s")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                        "--cuda-device-only", "-S", "-o", out, src], stderr=subprocess.DEVNULL)
 want = sys.argv[1] if len(sys.argv) > 1 else "k_intersectILb1"
 minn = int(sys.argv[2]) if len(sys.argv) > 2 else 12
