@@ -772,6 +772,159 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   }
 }
 
+// ── candidate ring with carry-over (fused kernels) ────────────────────────────────────────
+// In the fused kernels the candidates of consecutive groups share one per-wave FIFO ring: a primitive-
+// test chunk is run whenever 64 entries are pending, and what is left at the end of a group's search
+// (< 64 entries) waits for the next group's candidates instead of being run as a mostly empty chunk.
+// A typical depth->=1 group produces ~55 cube + ~12 sphere candidates — one entry too many for one wave —
+// so without carry-over every group paid a full cube chunk plus a sphere chunk at ~15 % lane occupancy.
+// Entries carry their ray (6 floats) and the parity of their group; results (closest-hit keys and
+// records) are double-buffered by parity, and a group is shaded one loop iteration later, after every
+// entry appended during its search has been processed (forced partial chunk only if the ring never
+// filled up in between).  Order of evaluation still does not matter: the (t, leaf) key minimum is the
+// reference's choice.
+constexpr int kRing = 128;  // ring entries per wave (power of two; <= 63 pending + <= 64 appended at once)
+struct Carry {
+  unsigned long long* best;  // [2][64]
+  float* rec;                // [2][6][64]  normal xyz, point xyz
+  uint32_t* ent;             // [kRing]     (leaf << 7) | (parity << 6) | owner lane
+  float* ray;                // [6][kRing]  origin xyz, direction xyz of the entry's ray
+  int head, count;           // wave-uniform
+  int appended, processed;   // running totals (wave-uniform)
+};
+PT_DEV Carry carry_init(char* base) {
+  Carry c;
+  c.best = reinterpret_cast<unsigned long long*>(base);
+  c.rec = reinterpret_cast<float*>(base + 2 * 64 * 8);
+  c.ent = reinterpret_cast<uint32_t*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4);
+  c.ray = reinterpret_cast<float*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4);
+  c.head = c.count = c.appended = c.processed = 0;
+  return c;
+}
+// Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
+PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__ nodes,
+                        const ptd::Geom* __restrict__ geoms) {
+  const bool valid = lane < n;
+  const int idx = (c.head + lane) & (kRing - 1);
+  const uint32_t entry = c.ent[idx];
+  const int src = (int)(entry & 63u);
+  const int par = (int)((entry >> 6) & 1u);
+  const uint32_t leaf = entry >> 7;
+  const f3 ro = mk(c.ray[0 * kRing + idx], c.ray[1 * kRing + idx], c.ray[2 * kRing + idx]);
+  const f3 rd = mk(c.ray[3 * kRing + idx], c.ray[4 * kRing + idx], c.ray[5 * kRing + idx]);
+  const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
+  f3 pt, nrm;
+  const float t = geom_test<-1>(G, ro, rd, pt, nrm);  // cube / sphere decided per lane; shared pre and post parts
+  const uint32_t tb = __float_as_uint(t);
+  if (valid && t > 0.f && tb < 0x7f7fffffu) {
+    const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
+    unsigned long long* slot = &c.best[par * 64 + src];
+    atomicMin(slot, key);
+    if (*slot == key) {  // this candidate is the ray's best so far: publish its record
+      float* r = c.rec + par * 6 * 64 + src;
+      r[0 * 64] = nrm.x, r[1 * 64] = nrm.y, r[2 * 64] = nrm.z;
+      r[3 * 64] = pt.x, r[4 * 64] = pt.y, r[5 * 64] = pt.z;
+    }
+  }
+  c.head = (c.head + n) & (kRing - 1);
+  c.count -= n;
+  c.processed += n;
+}
+// Append the lanes with `pass` (entry: leaf index, group parity, own lane, own ray); runs a chunk as soon
+// as 64 entries are pending.  Wave-uniform control flow.
+PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int lane, f3 o, f3 d,
+                         const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+  const unsigned long long m = __ballot(pass);
+  if (!m) return;
+  const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+  if (pass) {
+    const int idx = (c.head + c.count + rank) & (kRing - 1);
+    c.ent[idx] = (leaf << 7) | ((uint32_t)par << 6) | (uint32_t)lane;
+    c.ray[0 * kRing + idx] = o.x, c.ray[1 * kRing + idx] = o.y, c.ray[2 * kRing + idx] = o.z;
+    c.ray[3 * kRing + idx] = d.x, c.ray[4 * kRing + idx] = d.y, c.ray[5 * kRing + idx] = d.z;
+  }
+  const int cnt = __popcll(m);
+  c.count += cnt;
+  c.appended += cnt;
+  if (c.count >= 64) carry_chunk(c, 64, lane, nodes, geoms);
+}
+// Candidate search of one group (phase 1 of trace_group) feeding the ring.
+PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
+                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
+  const RayInv ri = ray_inv(d);
+  float4 A = top[0], B = top[1];
+  for (int e = 0; e < ntop; ++e) {
+    const float4 TA = A, TB = B;  // bmin.xyz, bmax.x | bmax.yz, idx, link
+    if (e + 1 < ntop) A = top[2 * e + 2], B = top[2 * e + 3];
+    const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
+    const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
+    const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
+    if (t_link < 0) {
+      carry_append(c, pass, (uint32_t)t_idx, par, lane, o, d, nodes, geoms);
+    } else {  // subtree [idx, link): stackless scan, lanes that did not enter idle
+      int cur = pass ? t_idx : t_link;
+      while (__ballot(cur < t_link)) {
+        const bool act = cur < t_link;
+        const int at_n = act ? cur : t_idx;
+        const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
+        const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
+        const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
+        carry_append(c, in && __float_as_int(NB.w) >= 0, (uint32_t)at_n, par, lane, o, d, nodes, geoms);
+        if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
+      }
+    }
+  }
+}
+// Make sure everything appended up to `mark` has been tested (only runs a partial chunk when the ring
+// did not fill up since).
+PT_DEV void carry_drain_to(Carry& c, int mark, int lane, const ptd::Node* __restrict__ nodes,
+                           const ptd::Geom* __restrict__ geoms) {
+  while (c.processed - mark < 0) carry_chunk(c, min(64, c.count), lane, nodes, geoms);
+}
+
+// State of a group between its search and its shading (one loop iteration later).
+struct Pending {
+  f3 d, c;
+  int slot;
+  bool valid;
+  int par, mark;
+  bool any;  // wave-uniform: a group is pending
+};
+// Shading + retirement + compaction of a pending group from its resolved hit keys/records.
+PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __restrict__ mats,
+                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
+                          int depth, float inv_n, int64_t FS, float* __restrict__ final_rgb,
+                          int32_t* __restrict__ counter, int64_t qbase, ptd::PathBuf out, int lane) {
+  const unsigned long long best = cy.best[pg.par * 64 + lane];
+  const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+  ShadeIO s;
+  s.o = mk(0.f, 0.f, 0.f);
+  s.d = pg.d;
+  s.c = pg.c;
+  s.alive = false;
+  Bounce bo;
+  bo.kind = 0;
+  f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+  if (pg.valid) {
+    float ht = -1.0f;
+    int hmat = 0;
+    if (hit) {
+      ht = __uint_as_float((uint32_t)(best >> 32));
+      hmat = geoms[nodes[(uint32_t)best].geom].material;
+      const float* r = cy.rec + pg.par * 6 * 64 + lane;
+      hn = mk(r[0 * 64], r[1 * 64], r[2 * 64]);
+      hp = mk(r[3 * 64], r[4 * 64], r[5 * 64]);
+    }
+    int k, p;
+    divmod(pg.slot, b.N, inv_n, k, p);
+    bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, global_pixel(b, p), ht, hmat, s);
+  }
+  const Reservation res = retire_and_reserve(pg.valid, s, pg.slot, FS, final_rgb, counter, lane);
+  const bool alive = pg.valid && s.alive;
+  if (alive) shade_bounce(bo, hn, hp, s);
+  emit_survivors(res, alive, s, pg.slot, qbase, out);
+}
+
 // ── depth 0 fused: generateRayFromCamera + computeIntersections + shadeAndExtendRays ────────
 // Primary rays are a pure function of the sample id, so depth 0 needs no path state in memory at
 // all: the ray is built in registers, traced with the same wave-cooperative search, shaded, and
@@ -902,13 +1055,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
   }
   __syncthreads();
   const int wib = threadIdx.x >> 6;
-  WaveLds w;
-  {
-    char* base = lds + tbl + wib * kWaveLds;
-    w.best = reinterpret_cast<unsigned long long*>(base);
-    w.rec = reinterpret_cast<float*>(base + 64 * 8);
-    w.list = reinterpret_cast<uint32_t*>(base + 64 * 8 + 7 * 64 * 4);
-  }
+  Carry cy = carry_init(lds + tbl + wib * kWaveLds2);
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
@@ -933,40 +1080,33 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     return v;
   };
   In nx = load(r * 64 + lane);
-  for (int j = r; j * 64 < n_q; j += wq) {
+  Pending pg;
+  pg.any = false;
+  int it = 0;
+  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
+  for (int j = r; j * 64 < n_q; j += wq, ++it) {
     const int i = j * 64 + lane;
     const bool valid = i < n_q;
     const In cur = nx;
-    nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is traced and shaded
-    trace_group(w, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane);
-    const unsigned long long best = w.best[lane];
-    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
-    ShadeIO s;
-    s.o = cur.o;
-    s.d = cur.d;
-    s.c = cur.c;
-    s.alive = false;
-    const int slot = cur.slot;
-    Bounce bo;
-    bo.kind = 0;
-    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
-    if (valid) {
-      float ht = -1.0f;
-      int hmat = 0;
-      if (hit) {
-        ht = __uint_as_float((uint32_t)(best >> 32));
-        hmat = geoms[nodes[(uint32_t)best].geom].material;
-        hn = mk(w.rec[0 * 64 + lane], w.rec[1 * 64 + lane], w.rec[2 * 64 + lane]);
-        hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
-      }
-      int k, p;
-      divmod(slot, b.N, inv_n, k, p);
-      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, global_pixel(b, p), ht, hmat, s);
+    nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is searched
+    const int par = it & 1;
+    cy.best[par * 64 + lane] = kNoHit;
+    carry_search(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par);
+    if (pg.any) {  // the previous group: all of its candidates are resolved once the ring has passed its mark
+      carry_drain_to(cy, pg.mark, lane, nodes, geoms);
+      shade_pending(cy, pg, mats, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
     }
-    const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
-    const bool alive = valid && s.alive;
-    if (alive) shade_bounce(bo, hn, hp, s);
-    emit_survivors(res, alive, s, slot, qbase, out);
+    pg.d = cur.d;
+    pg.c = cur.c;
+    pg.slot = cur.slot;
+    pg.valid = valid;
+    pg.par = par;
+    pg.mark = cy.appended;
+    pg.any = true;
+  }
+  if (pg.any) {
+    carry_drain_to(cy, pg.mark, lane, nodes, geoms);
+    shade_pending(cy, pg, mats, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
   }
 }
 
@@ -1050,7 +1190,7 @@ inline int round16(int x) { return (x + 15) & ~15; }
 }  // namespace
 
 // ───────────────────────────── launch wrappers ─────────────────────────────
-static int primary_lds_bytes(const SceneTables& sc, bool in_lds);
+static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds);
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
   int n = 0;
   hipError_t e = hipSuccess;
@@ -1070,12 +1210,12 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false>, kBlock, 0);
       break;
     case kPrimary:
-      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, primary_lds_bytes(sc, true));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, primary_lds_bytes(sc, false));
+      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds));
       break;
     case kBounce:
-      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, primary_lds_bytes(sc, true));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, primary_lds_bytes(sc, false));
+      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2));
       break;
     case kShade:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)));
@@ -1104,8 +1244,8 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
   else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), wave_lds, s, sc, qs, cnt_in, paths, hits);
 }
 
-static int primary_lds_bytes(const SceneTables& sc, bool in_lds) {
-  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * kWaveLds;
+static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds) {
+  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds;
   if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
   return bytes;
 }
@@ -1113,16 +1253,16 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
                     const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float* final_rgb) {
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
   const bool in_lds = bytes <= kLdsTableBytes;
-  if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, false), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
+  if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
 }
 
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                    const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float* final_rgb) {
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
   const bool in_lds = bytes <= kLdsTableBytes;
-  if (in_lds) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, true), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
-  else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), primary_lds_bytes(sc, false), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
+  if (in_lds) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
+  else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
 }
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
