@@ -239,6 +239,7 @@ int run_batch(int iter_first, int kb) {
   b.N = g.N;
   b.pixel_begin = g.pixel_begin;
   b.trace_depth = g.depth;
+  b.debug = g.debug_flags;
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;
   b.inv_stripe = g.stripe ? 1.0f / (float)g.stripe : 0.0f;

@@ -36,6 +36,7 @@ struct BatchInfo {
   int32_t stripe, gap;
   float inv_stripe;
   int32_t trace_depth;
+  int32_t debug;  // profiling ablations (wrong results): 4 = skip primitive tests, 8 = skip shade_bounce
 };
 
 // generateRayFromCamera for all K*N samples of a batch, straight into the queues.

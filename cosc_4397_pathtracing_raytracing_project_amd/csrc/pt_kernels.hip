@@ -661,10 +661,12 @@ PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
   const double Y2 = spec ? (double)2.0f * kPi * (double)r3 : (double)phi;
   float sX, cX;
   ptmath::sincosf32(X, &sX, &cX);
-  const double c1 = ptmath::cos64(Y1);
-  const double s2 = ptmath::sin64(Y2);
-  const float x = spec ? (float)((double)sX * c1) : sX * (float)c1;
-  const float z = spec ? (float)((double)sX * s2) : sX * (float)s2;
+  const float c1 = ptmath::cos_r(Y1);
+  const float s2 = ptmath::sin_r(Y2);
+  // specular: float(double(sX) * double(c1)) — the double product of two floats is exact, so it rounds
+  // to the same value as the float product the diffuse branch forms
+  const float x = sX * c1;
+  const float z = sX * s2;
   const float y = cX;
   f3 tangent, bitangent;
   local_frame(f, tangent, bitangent);
@@ -791,6 +793,7 @@ struct Carry {
   float* ray;                // [6][kRing]  origin xyz, direction xyz of the entry's ray
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
+  int debug;                 // BatchInfo::debug
 };
 PT_DEV Carry carry_init(char* base) {
   Carry c;
@@ -799,6 +802,7 @@ PT_DEV Carry carry_init(char* base) {
   c.ent = reinterpret_cast<uint32_t*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4);
   c.ray = reinterpret_cast<float*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4);
   c.head = c.count = c.appended = c.processed = 0;
+  c.debug = 0;
   return c;
 }
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
@@ -813,8 +817,9 @@ PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__
   const f3 ro = mk(c.ray[0 * kRing + idx], c.ray[1 * kRing + idx], c.ray[2 * kRing + idx]);
   const f3 rd = mk(c.ray[3 * kRing + idx], c.ray[4 * kRing + idx], c.ray[5 * kRing + idx]);
   const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
-  f3 pt, nrm;
-  const float t = geom_test<-1>(G, ro, rd, pt, nrm);  // cube / sphere decided per lane; shared pre and post parts
+  f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
+  float t = -1.0f;
+  if (!(c.debug & 4)) t = geom_test<-1>(G, ro, rd, pt, nrm);  // cube / sphere decided per lane; shared pre and post parts
   const uint32_t tb = __float_as_uint(t);
   if (valid && t > 0.f && tb < 0x7f7fffffu) {
     const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
@@ -921,7 +926,7 @@ PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __
   }
   const Reservation res = retire_and_reserve(pg.valid, s, pg.slot, FS, final_rgb, counter, lane);
   const bool alive = pg.valid && s.alive;
-  if (alive) shade_bounce(bo, hn, hp, s);
+  if (alive && !(b.debug & 8)) shade_bounce(bo, hn, hp, s);
   emit_survivors(res, alive, s, pg.slot, qbase, out);
 }
 
@@ -1056,6 +1061,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
   __syncthreads();
   const int wib = threadIdx.x >> 6;
   Carry cy = carry_init(lds + tbl + wib * kWaveLds2);
+  cy.debug = b.debug;
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();

@@ -5,17 +5,18 @@
 // the GPU, glibc on the host).  Those differ in the last ulp between vendors, so
 // no two builds of the reference agree bit-for-bit.  To make "GPU == CPU oracle"
 // a bit-exact statement, both sides evaluate these three functions with the SAME
-// sequence of IEEE-754 operations written out here: for sin/cos double-precision argument
-// reduction + fixed polynomials (the classic fdlibm kernel coefficients), for acos the
-// fdlibm float algorithm; only +,-,*,/,sqrt,rint and explicit fma().  Every one of those is correctly rounded
+// sequence of IEEE-754 operations written out here: for sin/cos a double-precision argument
+// reduction + fixed float polynomials, for acos the fdlibm float algorithm; only
+// +,-,*,/,sqrt,rint and explicit fma().  Every one of those is correctly rounded
 // on gfx950 (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt, f64 IEEE)
 // and on x86-64, so the results are identical on both.
 //
-// Accuracy: sin/cos are evaluated in double (within ~1 ulp(double) of the true value), so
-// their float-returning wrappers are correctly rounded except for ~1e-8 of inputs; acosf is
-// the fdlibm float algorithm (< 1 ulp, bit-identical to glibc's acosf).  Either way the
-// results are at least as close to CUDA's / glibc's sinf/cosf/acosf as those are to each
-// other.  tests/test_portable_math.py measures this against libm.
+// Accuracy: sin/cos use a double-precision argument reduction and float polynomial kernels
+// (<= 1 ulp, 2 ulp for 1.5e-5 of cos arguments); acosf is the fdlibm float algorithm (< 1 ulp,
+// bit-identical to glibc's acosf).  That is the accuracy class of the functions the reference
+// itself calls (CUDA documents 2 ulp for sinf/cosf, glibc's are < 1 ulp), so the results are as
+// close to a CUDA or a glibc build of the reference as those two are to each other.
+// tests/test_portable_math.py measures this against libm.
 //
 // The file is plain C++ with no dependencies; `PT_HD` expands to
 // `__host__ __device__` under hipcc.
@@ -29,76 +30,55 @@
 
 namespace ptmath {
 
-// fused multiply-add, exact on both sides (v_fma_f64 / libm or vfmadd).
+// fused multiply-adds, exact on both sides (v_fma_f64 / v_fma_f32; libm or vfmadd on the host).
 PT_HD double fma64(double a, double b, double c) { return __builtin_fma(a, b, c); }
+PT_HD float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// sin(r), cos(r) for |r| <= pi/4 (+ a hair).  Horner in z = r*r.
-PT_HD double ksin(double r) {
-  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  double z = r * r;
-  double p = fma64(z, S6, S5);
-  p = fma64(z, p, S4);
-  p = fma64(z, p, S3);
-  p = fma64(z, p, S2);
-  p = fma64(z, p, S1);
-  return fma64(r * z, p, r);
-}
-
-PT_HD double kcos(double r) {
-  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  double z = r * r;
-  double p = fma64(z, C6, C5);
-  p = fma64(z, p, C4);
-  p = fma64(z, p, C3);
-  p = fma64(z, p, C2);
-  p = fma64(z, p, C1);
-  // 1 - z/2 + z*z*p
-  return fma64(z * z, p, fma64(z, -0.5, 1.0));
-}
-
-// Reduce x to r in [-pi/4, pi/4] and quadrant q (0..3).  Valid for |x| < ~1e6
-// (the renderer only passes [0, 2*pi]).
-PT_HD double reduce_pio2(double x, int* q) {
+// sin and cos of x (|x| < ~1e6; the renderer passes [0, 2*pi]), x given in double because the
+// reference's specular branch forms its arguments in double (2.0f*M_PI*u, pathtrace.cu:411-413).
+//   1. argument reduction in double: k = rint(x*2/pi), r = x - k*pi/2 (two-term Cody-Waite, the
+//      product k*PIO2_1 is exact) — four f64 operations, so r is accurate to ~1e-17 even for the
+//      double arguments and no precision is lost near multiples of pi/2;
+//   2. r is rounded to float once, and sin(r), cos(r) on [-pi/4, pi/4] are evaluated in float with
+//      fma Horner chains (near-minimax degree-9 / degree-8 polynomials, Chebyshev fit of the Taylor
+//      series): float polynomials cost a quarter of the double-precision ones on gfx950's VALU.
+// Accuracy against the correctly rounded float value, measured over all 2^24 arguments 2*pi*i/2^24 and
+// over [0, pi/2]: sin <= 1 ulp everywhere (78.7 % exact), cos <= 1 ulp except 248 arguments with 2 ulp
+// (73.2 % exact).  CUDA documents 2 ulp for its sinf/cosf and glibc's are within 1 ulp, so this is the
+// same accuracy class as what the reference itself runs on.
+PT_HD void sincos_r(double x, float* s_out, float* c_out) {
   const double INV_PIO2 = 6.36619772367581382433e-01;
   const double PIO2_1 = 1.57079632673412561417e+00;   // first 33 bits of pi/2
   const double PIO2_1T = 6.07710050650619224932e-11;  // pi/2 - PIO2_1
-  double k = __builtin_rint(x * INV_PIO2);
-  double r = fma64(k, -PIO2_1, x);  // exact: k*PIO2_1 has <= 53 bits
-  r = fma64(k, -PIO2_1T, r);
-  *q = ((int)k) & 3;
-  return r;
-}
-
-PT_HD double sin64(double x) {
-  int q;
-  double r = reduce_pio2(x, &q);
-  double s = ksin(r), c = kcos(r);
-  double v = (q & 1) ? c : s;
-  return (q & 2) ? -v : v;
-}
-
-PT_HD double cos64(double x) {
-  int q;
-  double r = reduce_pio2(x, &q);
-  double s = ksin(r), c = kcos(r);
-  double v = (q & 1) ? s : c;
-  return ((q + 1) & 2) ? -v : v;
-}
-
-// sin and cos of the same argument with one reduction and one pair of kernels; bit-identical to
-// calling sin64 and cos64 separately (same operations on the same values).
-PT_HD void sincos64(double x, double* s_out, double* c_out) {
-  int q;
-  double r = reduce_pio2(x, &q);
-  double s = ksin(r), c = kcos(r);
-  double vs = (q & 1) ? c : s;
-  double vc = (q & 1) ? s : c;
+  const double k = __builtin_rint(x * INV_PIO2);
+  double rd = fma64(k, -PIO2_1, x);  // exact: k*PIO2_1 has <= 53 bits
+  rd = fma64(k, -PIO2_1T, rd);
+  const int q = ((int)k) & 3;
+  const float r = (float)rd, z = r * r;
+  const float S1 = -1.666666666e-01f, S2 = 8.333331871e-03f, S3 = -1.984008473e-04f, S4 = 2.724965793e-06f;
+  const float C1 = 4.166666666e-02f, C2 = -1.388888767e-03f, C3 = 2.480059866e-05f, C4 = -2.730073108e-07f;
+  float ps = fma32(z, S4, S3);
+  ps = fma32(z, ps, S2);
+  ps = fma32(z, ps, S1);
+  const float s = fma32(r * z, ps, r);                          // r + r*z*(S1 + z*(S2 + z*(S3 + z*S4)))
+  float pc = fma32(z, C4, C3);
+  pc = fma32(z, pc, C2);
+  pc = fma32(z, pc, C1);
+  const float c = fma32(z * z, pc, fma32(z, -0.5f, 1.0f));      // 1 - z/2 + z*z*(C1 + z*(C2 + z*(C3 + z*C4)))
+  const float vs = (q & 1) ? c : s;
+  const float vc = (q & 1) ? s : c;
   *s_out = (q & 2) ? -vs : vs;
   *c_out = ((q + 1) & 2) ? -vc : vc;
+}
+PT_HD float sin_r(double x) {
+  float s, c;
+  sincos_r(x, &s, &c);
+  return s;
+}
+PT_HD float cos_r(double x) {
+  float s, c;
+  sincos_r(x, &s, &c);
+  return c;
 }
 
 // acosf: the classic fdlibm single-precision algorithm (rational approximation of asin on
@@ -146,15 +126,9 @@ PT_HD float acosf32(float x) {
   return 2.0f * (df + w);
 }
 
-// float wrappers (what the renderer calls where the reference calls the float
-// overloads of sin/cos/acos).
-PT_HD float sinf32(float x) { return (float)sin64((double)x); }
-PT_HD float cosf32(float x) { return (float)cos64((double)x); }
-PT_HD void sincosf32(float x, float* s, float* c) {
-  double ds, dc;
-  sincos64((double)x, &ds, &dc);
-  *s = (float)ds;
-  *c = (float)dc;
-}
+// float wrappers (what the renderer calls where the reference calls the float overloads)
+PT_HD float sinf32(float x) { return sin_r((double)x); }
+PT_HD float cosf32(float x) { return cos_r((double)x); }
+PT_HD void sincosf32(float x, float* s, float* c) { sincos_r((double)x, s, c); }
 
 }  // namespace ptmath

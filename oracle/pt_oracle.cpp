@@ -594,8 +594,8 @@ static int g_math_mode = 0;
 static inline float m_sinf(float x) { return g_math_mode ? ptmath::sinf32(x) : sinf(x); }
 static inline float m_cosf(float x) { return g_math_mode ? ptmath::cosf32(x) : cosf(x); }
 static inline float m_acosf(float x) { return g_math_mode ? ptmath::acosf32(x) : acosf(x); }
-static inline double m_sin(double x) { return g_math_mode ? ptmath::sin64(x) : sin(x); }
-static inline double m_cos(double x) { return g_math_mode ? ptmath::cos64(x) : cos(x); }
+static inline double m_sin(double x) { return g_math_mode ? (double)ptmath::sin_r(x) : sin(x); }
+static inline double m_cos(double x) { return g_math_mode ? (double)ptmath::cos_r(x) : cos(x); }
 
 // ───────────────────────── intersection (src/intersections.h, pathtrace.cu:113-128) ─
 struct Ray {
