@@ -9,7 +9,7 @@ namespace ptk {
 constexpr int kBlock = 256;        // 4 wave64 per workgroup
 constexpr int kWavesPerBlock = 4;
 constexpr int kLdsTableBytes = 64 * 1024;  // scene tables are staged in LDS up to this size
-constexpr int kMaxTop = 24;                // entries in the flattened BVH top
+constexpr int kMaxTop = 32;                // entries in the flattened BVH top (per-lane 32-bit subtree mask)
 constexpr int kCandCap = 192;              // per-wave candidate list entries (LDS)
 constexpr int kWaveLds = 64 * 8 + 7 * 64 * 4 + kCandCap * 4;  // best keys + winner records + list = 3072 B
 // fused kernels: double-buffered keys/records + candidate ring with rays (see Carry) = 7680 B per wave

@@ -426,6 +426,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
   const RayInv ri = ray_inv(d);
   w.best[lane] = kNoHit;
   int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
+  uint32_t pend = 0;   // per lane: top entries that are subtrees and whose box this ray passes
 
   // top list: wave-uniform LDS reads (broadcast), entry e+1 fetched while entry e is tested
   float4 A = top[0], B = top[1];
@@ -453,35 +454,47 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
           ns += cnt;
         }
       }
-    } else {  // subtree [idx, link): stackless scan, lanes that did not enter idle
-      int cur = pass ? t_idx : t_link;
-      while (__ballot(cur < t_link)) {
-        const bool act = cur < t_link;
-        const int at_n = act ? cur : t_idx;
-        const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
-        const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
-        const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
-        const int g = __float_as_int(NB.w);
-        const bool cand = in && g >= 0;
-        const bool cbox = cand && geoms[g].type == 1;
-        const bool csph = cand && !cbox;
-        const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
-        if (mb | msp) {
-          if (nb + ns + 128 > kCandCap) {
-            flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
-            nb = ns = 0;
-          }
-          const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)lane;
-          const int rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
-          const int rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(msp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msp, 0));
-          const int cb = __popcll(mb), cs = __popcll(msp);
-          if (cbox) w.list[nb + rb] = entry;
-          if (csph) w.list[kCandCap - ns - cs + rs] = entry;
-          nb += cb;
-          ns += cs;
-        }
-        if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
+    } else if (pass) {
+      pend |= 1u << e;
+    }
+  }
+  // subtrees below the cut: every lane walks its entered subtrees back to back, independently of the others
+  if (__ballot(pend != 0)) {
+    int cur = 0, end = 0;
+    while (true) {
+      if (cur >= end && pend) {
+        const int e = __builtin_ctz(pend);
+        pend &= pend - 1;
+        const float4 TB = top[2 * e + 1];
+        cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
+        end = __float_as_int(TB.w);
       }
+      const bool act = cur < end;
+      if (!__ballot(act)) break;
+      const int at_n = act ? cur : 0;
+      const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
+      const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
+      const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
+      const int g = __float_as_int(NB.w);
+      const bool cand = in && g >= 0;
+      const bool cbox = cand && geoms[g].type == 1;
+      const bool csph = cand && !cbox;
+      const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
+      if (mb | msp) {
+        if (nb + ns + 128 > kCandCap) {
+          flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+          nb = ns = 0;
+        }
+        const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)lane;
+        const int rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
+        const int rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(msp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msp, 0));
+        const int cb = __popcll(mb), cs = __popcll(msp);
+        if (cbox) w.list[nb + rb] = entry;
+        if (csph) w.list[kCandCap - ns - cs + rs] = entry;
+        nb += cb;
+        ns += cs;
+      }
+      if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
     }
   }
   if (nb + ns) flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
@@ -857,6 +870,7 @@ PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int lane, 
 PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
   const RayInv ri = ray_inv(d);
+  uint32_t pend = 0;  // per lane: top entries that are subtrees and whose box this ray passes
   float4 A = top[0], B = top[1];
   for (int e = 0; e < ntop; ++e) {
     const float4 TA = A, TB = B;  // bmin.xyz, bmax.x | bmax.yz, idx, link
@@ -864,19 +878,30 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
     const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
     const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
-    if (t_link < 0) {
-      carry_append(c, pass, (uint32_t)t_idx, par, lane, o, d, nodes, geoms);
-    } else {  // subtree [idx, link): stackless scan, lanes that did not enter idle
-      int cur = pass ? t_idx : t_link;
-      while (__ballot(cur < t_link)) {
-        const bool act = cur < t_link;
-        const int at_n = act ? cur : t_idx;
-        const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
-        const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
-        const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
-        carry_append(c, in && __float_as_int(NB.w) >= 0, (uint32_t)at_n, par, lane, o, d, nodes, geoms);
-        if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
+    if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, o, d, nodes, geoms);
+    else if (pass) pend |= 1u << e;
+  }
+  // Subtrees below the cut (large scenes only): every lane walks ITS entered subtrees back to back with the
+  // stackless scan, independently of the other lanes — the loop runs max-over-lanes of the lanes' total node
+  // visits, not the sum over subtrees of the per-subtree maxima.
+  if (__ballot(pend != 0)) {
+    int cur = 0, end = 0;
+    while (true) {
+      if (cur >= end && pend) {
+        const int e = __builtin_ctz(pend);
+        pend &= pend - 1;
+        const float4 TB = top[2 * e + 1];
+        cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
+        end = __float_as_int(TB.w);
       }
+      const bool act = cur < end;
+      if (!__ballot(act)) break;
+      const int at_n = act ? cur : 0;
+      const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
+      const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
+      const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
+      carry_append(c, in && __float_as_int(NB.w) >= 0, (uint32_t)at_n, par, lane, o, d, nodes, geoms);
+      if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
     }
   }
 }
