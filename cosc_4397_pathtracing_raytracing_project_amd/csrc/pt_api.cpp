@@ -69,6 +69,7 @@ struct Ctx {
   ptd::Mat* d_mats = nullptr;
   ptd::TopEntry* d_top = nullptr;
   int num_nodes = 0, num_top = 0;
+  float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
   bool legacy = false;
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
@@ -205,6 +206,8 @@ ptk::SceneTables tables() {
   t.num_mats = (int)g.mats.size();
   t.top = g.d_top;
   t.num_top = (g.debug_flags & 1) ? 0 : g.num_top;
+  std::memcpy(t.root_min, g.root_min, 12);
+  std::memcpy(t.root_max, g.root_max, 12);
   return t;
 }
 
@@ -467,6 +470,8 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   std::vector<ptd::TopEntry> top;
   build_top(ref_nodes, nodes, where, g.geoms, top);
   g.num_top = (int)top.size();
+  std::memcpy(g.root_min, ref_nodes[0].bmin, 12);
+  std::memcpy(g.root_max, ref_nodes[0].bmax, 12);
   g.legacy = opt.legacy_traversal != 0;
   g.debug_flags = opt.debug_flags;
   g.fuse_primary = !g.legacy && !opt.unfused_primary;

@@ -24,6 +24,7 @@ struct SceneTables {
   int32_t num_mats;
   const ptd::TopEntry* top;  // flattened BVH top (see ptd::TopEntry)
   int32_t num_top;
+  float root_min[3], root_max[3];  // bounds of the whole tree (reference node 0)
 };
 
 struct BatchInfo {

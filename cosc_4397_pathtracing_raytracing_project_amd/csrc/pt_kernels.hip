@@ -1023,7 +1023,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     divmod(slot, b.N, inv_n, k, pl);
     const int p = global_pixel(b, pl);  // global pixel index
     const f3 d = camera_dir(cam, inv_w, p);
-    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
+    // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
+    // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
+    // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
+    const bool near_scene = __ballot(valid && slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+                                                   sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
+    if (near_scene) trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
+    else w.best[lane] = kNoHit;
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
     ShadeIO s;
