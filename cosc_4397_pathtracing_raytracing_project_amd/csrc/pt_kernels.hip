@@ -1180,7 +1180,20 @@ __global__ __launch_bounds__(kBlock) void k_gather(BatchInfo b, const float* __r
   const int64_t FS = (int64_t)b.K * b.N;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < b.N; p += gridDim.x * blockDim.x) {
     float r = image[3 * (int64_t)p], g = image[3 * (int64_t)p + 1], bl = image[3 * (int64_t)p + 2];
-    for (int k = 0; k < b.K; ++k) {  // iteration order, like successive finalGather launches
+    // iteration order, like successive finalGather launches; loads are issued eight iterations at a time so
+    // that 24 of them are in flight per lane, the adds stay strictly sequential (float sums are order-dependent)
+    int k = 0;
+    for (; k + 8 <= b.K; k += 8) {
+      float vr[8], vg[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t s = (int64_t)(k + u) * b.N + p;
+        vr[u] = final_rgb[s], vg[u] = final_rgb[FS + s], vb[u] = final_rgb[2 * FS + s];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r += vr[u], g += vg[u], bl += vb[u];
+    }
+    for (; k < b.K; ++k) {
       const int64_t s = (int64_t)k * b.N + p;
       r += final_rgb[s];
       g += final_rgb[FS + s];
