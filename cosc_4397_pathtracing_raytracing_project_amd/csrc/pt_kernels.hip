@@ -11,6 +11,12 @@
 //                rule of SURVEY.md §8a and the compaction the reference never had
 //   k_gather     finalGather             src/pathtrace.cu:439-444
 //   k_preview    sendImageToPBO          src/pathtrace.cu:250-268
+// and the two kernels the default pipeline actually runs, which fuse the above per depth so that
+// neither the primary ray nor the hit record ever goes through HBM:
+//   k_primary    depth 0:  generate + intersect + shade + compaction
+//   k_bounce     depth >= 1: intersect + shade + compaction, candidate ring carried across groups
+// (k_generate / k_intersect / k_shade remain as the unfused form for stage-parity tests and A/B runs,
+// k_intersect_legacy as the per-lane tree walk the wave-cooperative search replaced.)
 //
 // Arithmetic contract: compiled with -ffp-contract=off; every float operation is
 // written in the order GLM 0.9.6 / the reference evaluate it, divisions and square
