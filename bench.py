@@ -222,6 +222,15 @@ def main() -> None:
                    "traversal": "legacy per-lane" if args.legacy_traversal else "wave-cooperative"},
         "roofline": roofline,
     }
+    # Context: the reference pipeline's own algorithmic traffic is 44 + 160*L + 40 B per sample
+    # (generate 44, intersect 56 + shade 104 per live segment, gather 40; L = live segments per sample), i.e. a
+    # ceiling of 8 TB/s / that figure if every stage streamed its records through HBM.  The fused kernels avoid
+    # most of that traffic, so the sample rate is also quoted as the HBM rate that pipeline would have needed.
+    L = float(live.sum()) / max(1, st.samples)
+    ref_bytes = 44.0 + 160.0 * L + 40.0
+    out["pipeline_equivalent"] = {"reference_pipeline_bytes_per_sample": round(ref_bytes, 1),
+                                  "equivalent_GBps": round(out["value"] * 1e6 * ref_bytes / 1e9 / max(1, world), 1),
+                                  "frac_of_hbm_peak_per_gpu": round(out["value"] * 1e6 * ref_bytes / 1e9 / max(1, world) / HBM_PEAK_GBS, 4)}
 
     if rank == 0 and world == 1 and not args.no_extras:
         img = full.cpu().numpy()
