@@ -219,3 +219,21 @@ def test_preview_and_png(scene_dir, tmp_path):
     exp = np.clip((np.power((img / np.float32(spp)).astype(np.float32), np.float32(1 / 2.2)) * 255).astype(np.int64), 0, 255)
     assert np.abs(rgba[:, :3].astype(np.int64) - exp).max() <= 1  # powf ulp
     assert (rgba[:, 3] == 0).all()
+
+
+@pytest.mark.parametrize("name,spp", [("cornell", 6), ("sphere", 8)])
+def test_reference_scene_files_render_bit_exact(oracle, name, spp):
+    """The reference's own scene files (tests/golden/scenes, verbatim data) at their own resolution and depth."""
+    path = os.path.join(HERE, "golden", "scenes", name + ".txt")
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    sc = capi.Scene(path)
+    w, h = sc.resolution
+    r = capi.Renderer(sc)
+    r.render(1, spp)
+    img = r.readback()
+    r.free()
+    oracle.set_math_mode(oracle.PORTABLE)
+    oracle.load_scene(path)
+    ref = oracle.render(1, spp, depth=sc.trace_depth, variant=oracle.RETIRE, nthreads=min(16, os.cpu_count() or 1))
+    assert img.shape == (w * h, 3)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))

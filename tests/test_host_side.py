@@ -136,3 +136,22 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(d, f), errors="replace").read()
                 assert "liboracle" not in txt and "oracle.binding" not in txt and "from oracle" not in txt, os.path.join(d, f)
+
+
+@pytest.mark.parametrize("name", ["cornell", "sphere"])
+def test_reference_scene_files_load_verbatim(oracle, name, scene_dir):
+    """tests/golden/scenes/*.txt are the reference's own scene data files (scenes/cornell.txt, scenes/sphere.txt,
+    comments included): the product loader and the oracle loader must build identical tables from them, and they
+    must equal what scenes.py synthesises (which is what the benchmark renders)."""
+    path = os.path.join(HERE, "golden", "scenes", name + ".txt")
+    sc = capi.Scene(path)
+    oracle.load_scene(path)
+    assert bytes(sc.desc.camera) == bytes(oracle.camera())
+    assert all(bytes(a) == bytes(b) for a, b in zip(sc.geoms(), oracle.geoms()))
+    assert all(bytes(a) == bytes(b) for a, b in zip(sc.materials(), oracle.materials()))
+    assert all(bytes(a) == bytes(b) for a, b in zip(sc.bvh(), oracle.bvh()))
+    syn = capi.Scene(scene_dir[name])
+    assert bytes(sc.desc.camera) == bytes(syn.desc.camera) and sc.desc.num_geoms == syn.desc.num_geoms
+    assert all(bytes(a) == bytes(b) for a, b in zip(sc.geoms(), syn.geoms()))
+    assert all(bytes(a) == bytes(b) for a, b in zip(sc.materials(), syn.materials()))
+    assert sc.iterations == syn.iterations and sc.trace_depth == syn.trace_depth and sc.image_name == syn.image_name
