@@ -70,6 +70,7 @@ struct Ctx {
   ptd::TopEntry* d_top = nullptr;
   int num_nodes = 0, num_top = 0;
   float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+  float cull_margin = 0.f;
   bool legacy = false;
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
@@ -208,6 +209,7 @@ ptk::SceneTables tables() {
   t.num_top = (g.debug_flags & 1) ? 0 : g.num_top;
   std::memcpy(t.root_min, g.root_min, 12);
   std::memcpy(t.root_max, g.root_max, 12);
+  t.cull_margin = (g.debug_flags & 16) ? INFINITY : g.cull_margin;
   return t;
 }
 
@@ -472,6 +474,20 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   g.num_top = (int)top.size();
   std::memcpy(g.root_min, ref_nodes[0].bmin, 12);
   std::memcpy(g.root_max, ref_nodes[0].bmax, 12);
+  {
+    // SceneTables::cull_margin: >= 10x the worst undershoot of a reported hit distance (1e-4 object units mapped
+    // to world space + rounding of the transforms at the scene's coordinate magnitudes)
+    float max_xf = 1.0f, extent = 1.0f;
+    for (const PtGeom& gm : g.geoms) {
+      float f = 0.f;
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) f += gm.transform[c * 4 + r] * gm.transform[c * 4 + r];
+      max_xf = std::max(max_xf, sqrtf(f));
+    }
+    for (int a = 0; a < 3; ++a)
+      extent = std::max({extent, fabsf(g.root_min[a]), fabsf(g.root_max[a]), fabsf(g.cam.position[a])});
+    g.cull_margin = 1e-3f * max_xf + 1e-4f * extent;
+  }
   g.legacy = opt.legacy_traversal != 0;
   g.debug_flags = opt.debug_flags;
   g.fuse_primary = !g.legacy && !opt.unfused_primary;

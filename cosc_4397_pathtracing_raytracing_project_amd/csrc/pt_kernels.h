@@ -25,6 +25,12 @@ struct SceneTables {
   const ptd::TopEntry* top;  // flattened BVH top (see ptd::TopEntry)
   int32_t num_top;
   float root_min[3], root_max[3];  // bounds of the whole tree (reference node 0)
+  // Closer-hit cull of the subtree scans: a box whose entry distance exceeds the ray's best hit distance so far
+  // by more than this margin cannot contain the closest hit.  The reported hit distance is measured to a point
+  // pulled 1e-4 object units towards the ray origin (intersections.h:27-29) and carries the rounding of two
+  // matrix products, so it can undershoot the true distance by 1e-4 * |transform| + O(1e-6 * |coordinates|); the
+  // host sets a margin an order of magnitude above that bound (pt_api.cpp).  Negative: culling disabled.
+  float cull_margin;
 };
 
 struct BatchInfo {

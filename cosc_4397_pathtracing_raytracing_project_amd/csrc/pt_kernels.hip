@@ -277,6 +277,20 @@ PT_DEV bool slab(f3 o, const RayInv& ri, float lox, float loy, float loz, float 
   return !(tmax <= tmin);
 }
 
+// slab() that also returns the entry distance (for the closer-hit cull of the subtree scans).
+PT_DEV bool slab_t(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn) {
+  const float t0x = ((ri.sx ? hix : lox) - o.x) * ri.ix;
+  const float t1x = ((ri.sx ? lox : hix) - o.x) * ri.ix;
+  const float t0y = ((ri.sy ? hiy : loy) - o.y) * ri.iy;
+  const float t1y = ((ri.sy ? loy : hiy) - o.y) * ri.iy;
+  const float t0z = ((ri.sz ? hiz : loz) - o.z) * ri.iz;
+  const float t1z = ((ri.sz ? loz : hiz) - o.z) * ri.iz;
+  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
+  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
+  tn = tmin;
+  return !(tmax <= tmin);
+}
+
 // Legacy traversal (kept for A/B measurements, PtOptions flag): one lane walks the threaded
 // tree and runs each primitive test as soon as the wave reaches it.
 PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const ptd::Geom* __restrict__ geoms, f3 o, f3 d) {
@@ -428,7 +442,7 @@ PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
 // w.best[lane] holds the lane's (t bits << 32 | leaf) key (kNoHit if none) and w.rec its normal/point.
 PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
-                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane) {
+                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull) {
   const RayInv ri = ray_inv(d);
   w.best[lane] = kNoHit;
   int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
@@ -480,7 +494,11 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const int at_n = act ? cur : 0;
       const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
       const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
-      const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
+      // closer-hit cull: a box entered beyond the ray's best hit so far (+ margin, see SceneTables::cull_margin)
+      // cannot hold the closest hit
+      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * lane + 1]) + cull;
+      float tn;
+      const bool in = act && slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
       const int g = __float_as_int(NB.w);
       const bool cand = in && g >= 0;
       const bool cbox = cand && geoms[g].type == 1;
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
       no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
       nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
     }
-    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
+    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin);
 
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -874,7 +892,7 @@ PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int lane, 
 }
 // Candidate search of one group (phase 1 of trace_group) feeding the ring.
 PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
-                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
+                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull) {
   const RayInv ri = ray_inv(d);
   uint32_t pend = 0;  // per lane: top entries that are subtrees and whose box this ray passes
   float4 A = top[0], B = top[1];
@@ -905,7 +923,9 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
       const int at_n = act ? cur : 0;
       const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
       const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
-      const bool in = act && slab(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y);
+      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + lane) + 1]) + cull;
+      float tn;
+      const bool in = act && slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
       carry_append(c, in && __float_as_int(NB.w) >= 0, (uint32_t)at_n, par, lane, o, d, nodes, geoms);
       if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
     }
@@ -1034,7 +1054,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
     const bool near_scene = __ballot(valid && slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (near_scene) trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane);
+    if (near_scene) trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin);
     else w.best[lane] = kNoHit;
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1134,7 +1154,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is searched
     const int par = it & 1;
     cy.best[par * 64 + lane] = kNoHit;
-    carry_search(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par);
+    carry_search(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin);
     if (pg.any) {  // the previous group: all of its candidates are resolved once the ring has passed its mark
       carry_drain_to(cy, pg.mark, lane, nodes, geoms);
       shade_pending(cy, pg, mats, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);

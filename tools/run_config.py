@@ -16,6 +16,7 @@ ap.add_argument("--grid", default="22,22,21")
 ap.add_argument("--check-rows", default="")
 ap.add_argument("--save", default="")
 ap.add_argument("--iters-per-batch", type=int, default=0)
+ap.add_argument("--debug-flags", type=int, default=0)
 a = ap.parse_args()
 w, h = map(int, a.res.split("x"))
 txt = {"cornell": scenes.cornell_scene_text, "sphere": scenes.sphere_scene_text}.get(a.scene)
@@ -23,9 +24,9 @@ text = txt(res=(w, h), depth=a.depth) if txt else scenes.stress_scene_text(tuple
 path = scenes.write_scene(text, os.path.join(tempfile.mkdtemp(), a.scene + ".txt"))
 sc = capi.Scene(path, res=(w, h))
 print(f"{a.scene}: {sc.desc.num_geoms} geoms, {len(sc.bvh())} BVH nodes, {w}x{h}, depth {sc.trace_depth}")
-r = capi.Renderer(sc, iters_per_batch=a.iters_per_batch, time_kernels=True)
+r = capi.Renderer(sc, iters_per_batch=a.iters_per_batch, time_kernels=True, debug_flags=a.debug_flags)
 r.render(1, max(2, a.spp // 10)); r.sync(); r.free()
-r = capi.Renderer(sc, iters_per_batch=a.iters_per_batch, time_kernels=True)
+r = capi.Renderer(sc, iters_per_batch=a.iters_per_batch, time_kernels=True, debug_flags=a.debug_flags)
 t0 = time.perf_counter(); r.render(1, a.spp); img = r.readback(); dt = time.perf_counter() - t0
 st = r.stats(); r.free()
 live = np.array(st.live_rays[:a.depth], float)
