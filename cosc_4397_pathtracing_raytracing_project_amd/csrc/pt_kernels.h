@@ -13,7 +13,7 @@ constexpr int kMaxTop = 32;                // entries in the flattened BVH top (
 constexpr int kCandCap = 192;              // per-wave candidate list entries (LDS)
 constexpr int kWaveLds = 64 * 8 + 7 * 64 * 4 + kCandCap * 4;  // best keys + winner records + list = 3072 B
 // fused kernels: double-buffered keys/records + candidate ring with rays (see Carry) = 7680 B per wave
-constexpr int kWaveLds2 = 2 * 64 * 8 + 2 * 6 * 64 * 4 + 128 * 4 + 6 * 128 * 4;
+constexpr int kWaveLds2 = 2 * 64 * 8 + 2 * 6 * 64 * 4 + 128 * 4 + 6 * 128 * 4 + 64 * 4;
 
 struct SceneTables {
   const ptd::Node* nodes;  // threaded DFS order

@@ -34,6 +34,12 @@ namespace {
 
 #define PT_DEV __device__ __forceinline__
 
+// Tuning switch of the large-scene (global-table) path, overridable with -D for A/B builds.
+#ifndef PT_STEAL_MIN
+#define PT_STEAL_MIN 16
+#endif
+constexpr int kStealMin = PT_STEAL_MIN;  // idle lanes needed before a work-stealing step is run (65: never)
+
 struct f3 {
   float x, y, z;
 };
@@ -291,6 +297,22 @@ PT_DEV bool slab_t(f3 o, const RayInv& ri, float lox, float loy, float loz, floa
   return !(tmax <= tmin);
 }
 
+// One step of a lane's stackless subtree scan.  On return `cur` is advanced, `cand` says whether the node is a
+// leaf whose box the ray passes (and that is not culled), `leaf` is its index in `nodes`, `geom` its geom index.
+// bt: the ray's best hit distance so far + SceneTables::cull_margin (closer-hit cull).
+PT_DEV void scan_step(const ptd::Node* __restrict__ nodes, f3 o, const RayInv& ri, bool act, int& cur, float bt,
+                      bool& cand, int& leaf, int& geom) {
+  const int at_n = act ? cur : 0;
+  const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
+  const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
+  float tn;
+  const bool in = act && slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
+  geom = __float_as_int(NB.w);
+  cand = in && geom >= 0;
+  leaf = at_n;
+  if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
+}
+
 // Legacy traversal (kept for A/B measurements, PtOptions flag): one lane walks the threaded
 // tree and runs each primitive test as soon as the wave reaches it.
 PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const ptd::Geom* __restrict__ geoms, f3 o, f3 d) {
@@ -491,17 +513,13 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       }
       const bool act = cur < end;
       if (!__ballot(act)) break;
-      const int at_n = act ? cur : 0;
-      const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
-      const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
       // closer-hit cull: a box entered beyond the ray's best hit so far (+ margin, see SceneTables::cull_margin)
       // cannot hold the closest hit
       const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * lane + 1]) + cull;
-      float tn;
-      const bool in = act && slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
-      const int g = __float_as_int(NB.w);
-      const bool cand = in && g >= 0;
-      const bool cbox = cand && geoms[g].type == 1;
+      bool cand;
+      int at_n, aux;
+      scan_step(nodes, o, ri, act, cur, bt, cand, at_n, aux);
+      const bool cbox = cand && geoms[aux].type == 1;
       const bool csph = cand && !cbox;
       const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
       if (mb | msp) {
@@ -518,7 +536,6 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
         nb += cb;
         ns += cs;
       }
-      if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
     }
   }
   if (nb + ns) flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
@@ -828,6 +845,7 @@ struct Carry {
   float* rec;                // [2][6][64]  normal xyz, point xyz
   uint32_t* ent;             // [kRing]     (leaf << 7) | (parity << 6) | owner lane
   float* ray;                // [6][kRing]  origin xyz, direction xyz of the entry's ray
+  int* slot;                 // [64]        scratch of the work-stealing step (carry_search)
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
   int debug;                 // BatchInfo::debug
@@ -838,6 +856,7 @@ PT_DEV Carry carry_init(char* base) {
   c.rec = reinterpret_cast<float*>(base + 2 * 64 * 8);
   c.ent = reinterpret_cast<uint32_t*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4);
   c.ray = reinterpret_cast<float*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4);
+  c.slot = reinterpret_cast<int*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4 + 6 * kRing * 4);
   c.head = c.count = c.appended = c.processed = 0;
   c.debug = 0;
   return c;
@@ -872,16 +891,16 @@ PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__
   c.count -= n;
   c.processed += n;
 }
-// Append the lanes with `pass` (entry: leaf index, group parity, own lane, own ray); runs a chunk as soon
+// Append the lanes with `pass` (entry: leaf index, group parity, lane that owns the ray, the ray); runs a chunk as soon
 // as 64 entries are pending.  Wave-uniform control flow.
-PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int lane, f3 o, f3 d,
+PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner, int lane, f3 o, f3 d,
                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const unsigned long long m = __ballot(pass);
   if (!m) return;
   const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   if (pass) {
     const int idx = (c.head + c.count + rank) & (kRing - 1);
-    c.ent[idx] = (leaf << 7) | ((uint32_t)par << 6) | (uint32_t)lane;
+    c.ent[idx] = (leaf << 7) | ((uint32_t)par << 6) | (uint32_t)owner;
     c.ray[0 * kRing + idx] = o.x, c.ray[1 * kRing + idx] = o.y, c.ray[2 * kRing + idx] = o.z;
     c.ray[3 * kRing + idx] = d.x, c.ray[4 * kRing + idx] = d.y, c.ray[5 * kRing + idx] = d.z;
   }
@@ -902,14 +921,20 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
     const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
     const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
-    if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, o, d, nodes, geoms);
+    if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, lane, o, d, nodes, geoms);
     else if (pass) pend |= 1u << e;
   }
-  // Subtrees below the cut (large scenes only): every lane walks ITS entered subtrees back to back with the
-  // stackless scan, independently of the other lanes — the loop runs max-over-lanes of the lanes' total node
-  // visits, not the sum over subtrees of the per-subtree maxima.
+  // Subtrees below the cut (large scenes only).  Every lane walks its own ray's entered subtrees back to back
+  // with the stackless scan, independently of the other lanes; lanes that run out of work STEAL a pending
+  // (ray, subtree) pair from a lane that still has some — the loop count of the wave is what bounds this phase
+  // (~60 VALU per step, lanes' totals range from 0 to several hundred node visits), so the goal is
+  // steps ~ total visits / 64 rather than the maximum over the lanes.  A stolen pair is walked with the donor's
+  // ray (fetched with ds_bpermute) and its candidates are filed under the donor's lane, so nothing downstream
+  // changes.  A lane only steals once its own list is empty, hence a donor's registers always hold its own ray.
   if (__ballot(pend != 0)) {
-    int cur = 0, end = 0;
+    int cur = 0, end = 0, own = lane;
+    f3 wo = o, wd = d;
+    RayInv wri = ri;
     while (true) {
       if (cur >= end && pend) {
         const int e = __builtin_ctz(pend);
@@ -918,16 +943,41 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
         cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
         end = __float_as_int(TB.w);
       }
+      const bool idle = cur >= end;
+      const unsigned long long I = __ballot(idle);
+      if (I == ~0ull) break;
+      if (__popcll(I) >= kStealMin) {
+        const unsigned long long Dn = __ballot(pend != 0);
+        if (Dn) {
+          const int nd = __popcll(Dn), ni = __popcll(I);
+          const int drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Dn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Dn, 0));
+          const int irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(I >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)I, 0));
+          if (pend != 0) c.slot[drank] = lane;  // the k-th donor's lane id
+          const bool take = idle && irank < nd;
+          const int donor = c.slot[take ? irank : 0];
+          const uint32_t dpend = (uint32_t)__builtin_amdgcn_ds_bpermute(donor << 2, (int)pend);
+          const f3 so = mk(bperm(donor, wo.x), bperm(donor, wo.y), bperm(donor, wo.z));
+          const f3 sd = mk(bperm(donor, wd.x), bperm(donor, wd.y), bperm(donor, wd.z));
+          const f3 si = mk(bperm(donor, wri.ix), bperm(donor, wri.iy), bperm(donor, wri.iz));
+          if (pend != 0 && drank < ni) pend &= pend - 1;  // given away
+          if (take) {
+            const int e = __builtin_ctz(dpend);
+            const float4 TB = top[2 * e + 1];
+            cur = __float_as_int(TB.z) + 1;
+            end = __float_as_int(TB.w);
+            own = donor;
+            wo = so, wd = sd;
+            wri.ix = si.x, wri.iy = si.y, wri.iz = si.z;
+            wri.sx = si.x < 0.0f, wri.sy = si.y < 0.0f, wri.sz = si.z < 0.0f;
+          }
+        }
+      }
       const bool act = cur < end;
-      if (!__ballot(act)) break;
-      const int at_n = act ? cur : 0;
-      const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
-      const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
-      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + lane) + 1]) + cull;
-      float tn;
-      const bool in = act && slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
-      carry_append(c, in && __float_as_int(NB.w) >= 0, (uint32_t)at_n, par, lane, o, d, nodes, geoms);
-      if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
+      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + own) + 1]) + cull;
+      bool cand;
+      int at_n, aux;
+      scan_step(nodes, wo, wri, act, cur, bt, cand, at_n, aux);
+      carry_append(c, cand, (uint32_t)at_n, par, own, lane, wo, wd, nodes, geoms);
     }
   }
 }

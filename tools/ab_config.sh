@@ -7,7 +7,7 @@ cp $DST /tmp/orig.so
 for round in 1 2; do
   for lib in "$@"; do
     cp $lib $DST
-    echo "round $round $(basename $lib): $(python tools/run_config.py $ARGS 2>&1 | grep -E 'Msamples|bit-exact' | cut -c1-60 | tr '\n' ' ')"
+    echo "round $round $(basename $lib): $(python tools/run_config.py $ARGS 2>&1 | grep -E 'Msamples|bit-exact' | sed -E 's/; live rays.*dominant kernel/; dominant kernel/; s/; K=.*//' | tr '\n' ' ')"
   done
 done
 cp /tmp/orig.so $DST
