@@ -71,6 +71,7 @@ struct Ctx {
   int num_nodes = 0, num_top = 0;
   float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
   float cull_margin = 0.f;
+  unsigned long long top_xor = 0;  // SceneTables::top_xor
   bool legacy = false;
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
@@ -151,29 +152,71 @@ void thread_bvh(const std::vector<PtBVHNode>& in, int idx, std::vector<ptd::Node
 }
 
 // Flatten the top of the tree into at most ptk::kMaxTop entries (see ptd::TopEntry): start from
-// the root and keep splitting the inner entry that covers the most nodes.
+// the root and keep splitting the inner entry that covers the most nodes.  The entries are emitted in
+// path-code order (0 = left child, 1 = right child, root choice in the most significant bit); when
+// the cut is a complete level (every entry at the same depth, a power of two of them) `top_xor`
+// receives, per direction-sign octant, the XOR mask that turns list order into near-first order
+// (pt_kernels.hip permute_xor), otherwise 0.
 void build_top(const std::vector<PtBVHNode>& ref, const std::vector<ptd::Node>& thr, const std::vector<int>& where,
-               const std::vector<PtGeom>& geoms, std::vector<ptd::TopEntry>& top) {
-  std::vector<int> cut{0};
+               const std::vector<PtGeom>& geoms, std::vector<ptd::TopEntry>& top, unsigned long long* top_xor) {
+  struct Cut {
+    int ref_idx;
+    uint32_t code;
+    int len;
+  };
+  std::vector<Cut> cut{{0, 0u, 0}};
   auto span = [&](int ref_idx) { return thr[where[ref_idx]].skip - where[ref_idx]; };
   while ((int)cut.size() < ptk::kMaxTop) {
     int best = -1;
     for (size_t i = 0; i < cut.size(); ++i)
-      if (ref[cut[i]].left >= 0 && (best < 0 || span(cut[i]) > span(cut[best]))) best = (int)i;
+      if (ref[cut[i].ref_idx].left >= 0 && cut[i].len < 24 && (best < 0 || span(cut[i].ref_idx) > span(cut[best].ref_idx)))
+        best = (int)i;
     if (best < 0) break;
-    const PtBVHNode n = ref[cut[best]];
-    cut[best] = n.right;
-    cut.push_back(n.left);
+    const Cut c = cut[best];
+    const PtBVHNode n = ref[c.ref_idx];
+    cut[best] = Cut{n.left, c.code << 1, c.len + 1};
+    cut.push_back(Cut{n.right, (c.code << 1) | 1u, c.len + 1});
   }
+  std::sort(cut.begin(), cut.end(), [](const Cut& a, const Cut& b) {
+    return ((uint64_t)a.code << (32 - a.len)) < ((uint64_t)b.code << (32 - b.len));
+  });
   top.clear();
-  for (int ref_idx : cut) {
-    const PtBVHNode& n = ref[ref_idx];
+  for (const Cut& c : cut) {
+    const PtBVHNode& n = ref[c.ref_idx];
     ptd::TopEntry e{};
     std::memcpy(e.bmin, n.bmin, 12);
     std::memcpy(e.bmax, n.bmax, 12);
-    e.idx = where[ref_idx];
-    e.link = n.left < 0 ? -1 - geoms[n.geomIndex].type : thr[where[ref_idx]].skip;
+    e.idx = where[c.ref_idx];
+    e.link = n.left < 0 ? -1 - geoms[n.geomIndex].type : thr[where[c.ref_idx]].skip;
     top.push_back(e);
+  }
+  *top_xor = 0;
+  const int levels = cut[0].len;
+  bool complete = levels >= 1 && levels <= 5 && (int)cut.size() == (1 << levels);
+  for (const Cut& c : cut) complete = complete && c.len == levels;
+  if (!complete) return;
+  // axis and polarity of each level, taken from the node on the all-left path
+  int axis[5] = {0, 0, 0, 0, 0};
+  bool left_lower[5] = {true, true, true, true, true};
+  int at = 0;
+  for (int l = 0; l < levels; ++l) {
+    const PtBVHNode &L = ref[ref[at].left], &R = ref[ref[at].right];
+    float sep = -1.f;
+    for (int a = 0; a < 3; ++a) {
+      const float d = fabsf((L.bmin[a] + L.bmax[a]) - (R.bmin[a] + R.bmax[a]));
+      if (d > sep) sep = d, axis[l] = a;
+    }
+    left_lower[l] = (L.bmin[axis[l]] + L.bmax[axis[l]]) <= (R.bmin[axis[l]] + R.bmax[axis[l]]);
+    at = ref[at].left;
+  }
+  for (int oct = 0; oct < 8; ++oct) {
+    uint32_t m = 0;
+    for (int l = 0; l < levels; ++l) {
+      const bool negative = (oct >> axis[l]) & 1;
+      const bool near_is_right = left_lower[l] == negative;  // positive direction: the lower child is nearer
+      if (near_is_right) m |= 1u << (levels - 1 - l);
+    }
+    *top_xor |= (unsigned long long)m << (8 * oct);
   }
 }
 
@@ -210,6 +253,7 @@ ptk::SceneTables tables() {
   std::memcpy(t.root_min, g.root_min, 12);
   std::memcpy(t.root_max, g.root_max, 12);
   t.cull_margin = (g.debug_flags & 16) ? INFINITY : g.cull_margin;
+  t.top_xor = (g.debug_flags & 32) ? 0ull : g.top_xor;
   return t;
 }
 
@@ -470,7 +514,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   thread_bvh(ref_nodes, 0, nodes, where);
   g.num_nodes = (int)nodes.size();
   std::vector<ptd::TopEntry> top;
-  build_top(ref_nodes, nodes, where, g.geoms, top);
+  build_top(ref_nodes, nodes, where, g.geoms, top, &g.top_xor);
   g.num_top = (int)top.size();
   std::memcpy(g.root_min, ref_nodes[0].bmin, 12);
   std::memcpy(g.root_max, ref_nodes[0].bmax, 12);

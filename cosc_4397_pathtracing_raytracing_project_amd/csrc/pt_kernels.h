@@ -31,6 +31,9 @@ struct SceneTables {
   // matrix products, so it can undershoot the true distance by 1e-4 * |transform| + O(1e-6 * |coordinates|); the
   // host sets a margin an order of magnitude above that bound (pt_api.cpp).  Negative: culling disabled.
   float cull_margin;
+  // Near-first subtree order: byte k = XOR mask for rays whose direction sign bits are k = sx | sy << 1 | sz << 2
+  // (pt_kernels.hip permute_xor); 0 when the top list is not a complete level of the tree.
+  unsigned long long top_xor;
 };
 
 struct BatchInfo {

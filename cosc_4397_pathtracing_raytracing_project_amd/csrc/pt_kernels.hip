@@ -297,6 +297,26 @@ PT_DEV bool slab_t(f3 o, const RayInv& ri, float lox, float loy, float loz, floa
   return !(tmax <= tmin);
 }
 
+// Near-first order of a ray's entered subtrees.  When the top list is a complete level of a balanced tree its
+// entries are laid out by path code (bit 4 = child taken at the root, ... bit 0 = at level 4; pt_api.cpp build_top),
+// so visiting the nearer child first at every level is visiting the entries in increasing (index XOR m) order,
+// where bit l of m says that the nearer child at that level is child 1 for this ray's direction signs
+// (SceneTables::top_xor, one mask per sign octant).  permute_xor returns the pending mask re-indexed by
+// j = e ^ m, so that ctz yields the entries nearest first; the cull then prunes the farther ones earlier.
+// Any m is valid (the order never changes results); m = 0 keeps the list order.
+PT_DEV uint32_t permute_xor(uint32_t x, uint32_t m) {
+  if (m & 1u) x = ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u);
+  if (m & 2u) x = ((x & 0x33333333u) << 2) | ((x >> 2) & 0x33333333u);
+  if (m & 4u) x = ((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu);
+  if (m & 8u) x = ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu);
+  if (m & 16u) x = (x << 16) | (x >> 16);
+  return x;
+}
+PT_DEV uint32_t octant_mask(const RayInv& ri, unsigned long long top_xor) {
+  const int oct = (int)ri.sx | ((int)ri.sy << 1) | ((int)ri.sz << 2);
+  return (uint32_t)(top_xor >> (oct * 8)) & 31u;
+}
+
 // One step of a lane's stackless subtree scan.  On return `cur` is advanced, `cand` says whether the node is a
 // leaf whose box the ray passes (and that is not culled), `leaf` is its index in `nodes`, `geom` its geom index.
 // bt: the ray's best hit distance so far + SceneTables::cull_margin (closer-hit cull).
@@ -464,7 +484,8 @@ PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
 // w.best[lane] holds the lane's (t bits << 32 | leaf) key (kNoHit if none) and w.rec its normal/point.
 PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
-                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull) {
+                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull,
+                        unsigned long long top_xor) {
   const RayInv ri = ray_inv(d);
   w.best[lane] = kNoHit;
   int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
@@ -503,9 +524,11 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
   // subtrees below the cut: every lane walks its entered subtrees back to back, independently of the others
   if (__ballot(pend != 0)) {
     int cur = 0, end = 0;
+    const uint32_t xm = octant_mask(ri, top_xor);
+    pend = permute_xor(pend, xm);
     while (true) {
       if (cur >= end && pend) {
-        const int e = __builtin_ctz(pend);
+        const int e = __builtin_ctz(pend) ^ (int)xm;
         pend &= pend - 1;
         const float4 TB = top[2 * e + 1];
         cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
@@ -601,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
       no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
       nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
     }
-    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin);
+    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
 
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -911,7 +934,8 @@ PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner,
 }
 // Candidate search of one group (phase 1 of trace_group) feeding the ring.
 PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
-                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull) {
+                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
+                         unsigned long long top_xor) {
   const RayInv ri = ray_inv(d);
   uint32_t pend = 0;  // per lane: top entries that are subtrees and whose box this ray passes
   float4 A = top[0], B = top[1];
@@ -935,9 +959,11 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
     int cur = 0, end = 0, own = lane;
     f3 wo = o, wd = d;
     RayInv wri = ri;
+    const uint32_t xm = octant_mask(ri, top_xor);  // near-first order of this ray's subtrees (permute_xor)
+    pend = permute_xor(pend, xm);
     while (true) {
       if (cur >= end && pend) {
-        const int e = __builtin_ctz(pend);
+        const int e = __builtin_ctz(pend) ^ (int)xm;
         pend &= pend - 1;
         const float4 TB = top[2 * e + 1];
         cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
@@ -956,12 +982,13 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
           const bool take = idle && irank < nd;
           const int donor = c.slot[take ? irank : 0];
           const uint32_t dpend = (uint32_t)__builtin_amdgcn_ds_bpermute(donor << 2, (int)pend);
+          const int dxm = __builtin_amdgcn_ds_bpermute(donor << 2, (int)xm);
           const f3 so = mk(bperm(donor, wo.x), bperm(donor, wo.y), bperm(donor, wo.z));
           const f3 sd = mk(bperm(donor, wd.x), bperm(donor, wd.y), bperm(donor, wd.z));
           const f3 si = mk(bperm(donor, wri.ix), bperm(donor, wri.iy), bperm(donor, wri.iz));
           if (pend != 0 && drank < ni) pend &= pend - 1;  // given away
           if (take) {
-            const int e = __builtin_ctz(dpend);
+            const int e = __builtin_ctz(dpend) ^ dxm;
             const float4 TB = top[2 * e + 1];
             cur = __float_as_int(TB.z) + 1;
             end = __float_as_int(TB.w);
@@ -1104,7 +1131,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
     const bool near_scene = __ballot(valid && slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (near_scene) trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin);
+    if (near_scene) trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
     else w.best[lane] = kNoHit;
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1204,7 +1231,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is searched
     const int par = it & 1;
     cy.best[par * 64 + lane] = kNoHit;
-    carry_search(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin);
+    carry_search(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
     if (pg.any) {  // the previous group: all of its candidates are resolved once the ring has passed its mark
       carry_drain_to(cy, pg.mark, lane, nodes, geoms);
       shade_pending(cy, pg, mats, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);

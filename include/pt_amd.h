@@ -90,7 +90,8 @@ typedef struct PtOptions {
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
   int32_t debug_flags;      /* profiling only, results are WRONG: bit0 intersect skips tracing (memory-side
                                floor of the kernel), bit1 shade skips shading (every path retires); bit4 (16) only disables
-                               the closer-hit cull of the subtree scans (results unchanged; A/B) */
+                               the closer-hit cull of the subtree scans, bit5 (32) only disables their near-first
+                               subtree order (results unchanged; A/B) */
   int32_t unfused_primary;  /* 1: run depth 0 as generate + intersect + shade launches instead of the fused
                                primary kernel (A/B and stage-parity runs) */
   int32_t unfused_bounces;  /* 1: depths >= 1 as separate computeIntersections + shade launches (hit records
