@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_legacy(SceneTables sc, ptd
 // the two phases are independent.
 struct WaveLds {
   unsigned long long* best;  // [64]
-  float* rec;                // [7][64]: normal xyz, point xyz (+1 spare row not allocated)
+  float* rec;                // [7][64]: normal xyz, point xyz; row 6: donor table of the work-stealing step
   uint32_t* list;            // [kCandCap]: (leaf index << 6) | owner lane
 };
 constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;  // t_min = FLT_MAX
@@ -521,9 +521,15 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       pend |= 1u << e;
     }
   }
-  // subtrees below the cut: every lane walks its entered subtrees back to back, independently of the others
+  // subtrees below the cut: every lane walks its entered subtrees back to back, independently of the others; lanes
+  // without work steal a pending (ray, subtree) pair from lanes that have several (see carry_search — same scheme;
+  // the donor table lives in the spare row of w.rec, candidates are filed under the owner's lane and the
+  // primitive tests fetch the ray from the owner's registers o, d as before)
   if (__ballot(pend != 0)) {
-    int cur = 0, end = 0;
+    int cur = 0, end = 0, own = lane;
+    f3 wo = o;
+    RayInv wri = ri;
+    int* slot = reinterpret_cast<int*>(w.rec + 6 * 64);
     const uint32_t xm = octant_mask(ri, top_xor);
     pend = permute_xor(pend, xm);
     while (true) {
@@ -534,14 +540,42 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
         cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
         end = __float_as_int(TB.w);
       }
+      const bool idle = cur >= end;
+      const unsigned long long I = __ballot(idle);
+      if (I == ~0ull) break;
+      if (__popcll(I) >= kStealMin) {
+        const unsigned long long Dn = __ballot(pend != 0);
+        if (Dn) {
+          const int nd = __popcll(Dn), ni = __popcll(I);
+          const int drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Dn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Dn, 0));
+          const int irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(I >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)I, 0));
+          if (pend != 0) slot[drank] = lane;
+          const bool take = idle && irank < nd;
+          const int donor = slot[take ? irank : 0];
+          const uint32_t dpend = (uint32_t)__builtin_amdgcn_ds_bpermute(donor << 2, (int)pend);
+          const int dxm = __builtin_amdgcn_ds_bpermute(donor << 2, (int)xm);
+          const f3 so = mk(bperm(donor, wo.x), bperm(donor, wo.y), bperm(donor, wo.z));
+          const f3 si = mk(bperm(donor, wri.ix), bperm(donor, wri.iy), bperm(donor, wri.iz));
+          if (pend != 0 && drank < ni) pend &= pend - 1;  // given away
+          if (take) {
+            const int e = __builtin_ctz(dpend) ^ dxm;
+            const float4 TB = top[2 * e + 1];
+            cur = __float_as_int(TB.z) + 1;
+            end = __float_as_int(TB.w);
+            own = donor;
+            wo = so;
+            wri.ix = si.x, wri.iy = si.y, wri.iz = si.z;
+            wri.sx = si.x < 0.0f, wri.sy = si.y < 0.0f, wri.sz = si.z < 0.0f;
+          }
+        }
+      }
       const bool act = cur < end;
-      if (!__ballot(act)) break;
       // closer-hit cull: a box entered beyond the ray's best hit so far (+ margin, see SceneTables::cull_margin)
       // cannot hold the closest hit
-      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * lane + 1]) + cull;
+      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * own + 1]) + cull;
       bool cand;
       int at_n, aux;
-      scan_step(nodes, o, ri, act, cur, bt, cand, at_n, aux);
+      scan_step(nodes, wo, wri, act, cur, bt, cand, at_n, aux);
       const bool cbox = cand && geoms[aux].type == 1;
       const bool csph = cand && !cbox;
       const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
@@ -550,7 +584,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
           flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
           nb = ns = 0;
         }
-        const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)lane;
+        const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)own;
         const int rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
         const int rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(msp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msp, 0));
         const int cb = __popcll(mb), cs = __popcll(msp);
