@@ -891,8 +891,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
 // (< 64 entries) waits for the next group's candidates instead of being run as a mostly empty chunk.
 // A typical depth->=1 group produces ~55 cube + ~12 sphere candidates — one entry too many for one wave —
 // so without carry-over every group paid a full cube chunk plus a sphere chunk at ~15 % lane occupancy.
-// Entries carry their ray (6 floats) and the parity of their group; results (closest-hit keys and
-// records) are double-buffered by parity, and a group is shaded one loop iteration later, after every
+// Entries carry the lane that owns their ray and the parity of their group; the rays themselves (6 floats), like
+// the results (closest-hit keys and records), are kept per lane and double-buffered by parity, and a group is shaded one loop iteration later, after every
 // entry appended during its search has been processed (forced partial chunk only if the ring never
 // filled up in between).  Order of evaluation still does not matter: the (t, leaf) key minimum is the
 // reference's choice.
@@ -901,7 +901,7 @@ struct Carry {
   unsigned long long* best;  // [2][64]
   float* rec;                // [2][6][64]  normal xyz, point xyz
   uint32_t* ent;             // [kRing]     (leaf << 7) | (parity << 6) | owner lane
-  float* ray;                // [6][kRing]  origin xyz, direction xyz of the entry's ray
+  float* ray;                // [2][6][64]  origin xyz, direction xyz of each lane's ray, by group parity
   int* slot;                 // [64]        scratch of the work-stealing step (carry_search)
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
@@ -913,7 +913,7 @@ PT_DEV Carry carry_init(char* base) {
   c.rec = reinterpret_cast<float*>(base + 2 * 64 * 8);
   c.ent = reinterpret_cast<uint32_t*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4);
   c.ray = reinterpret_cast<float*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4);
-  c.slot = reinterpret_cast<int*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4 + 6 * kRing * 4);
+  c.slot = reinterpret_cast<int*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4 + 2 * 6 * 64 * 4);
   c.head = c.count = c.appended = c.processed = 0;
   c.debug = 0;
   return c;
@@ -927,8 +927,9 @@ PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__
   const int src = (int)(entry & 63u);
   const int par = (int)((entry >> 6) & 1u);
   const uint32_t leaf = entry >> 7;
-  const f3 ro = mk(c.ray[0 * kRing + idx], c.ray[1 * kRing + idx], c.ray[2 * kRing + idx]);
-  const f3 rd = mk(c.ray[3 * kRing + idx], c.ray[4 * kRing + idx], c.ray[5 * kRing + idx]);
+  const float* ray = c.ray + par * 6 * 64 + src;
+  const f3 ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
+  const f3 rd = mk(ray[3 * 64], ray[4 * 64], ray[5 * 64]);
   const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
   f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
   float t = -1.0f;
@@ -948,9 +949,9 @@ PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__
   c.count -= n;
   c.processed += n;
 }
-// Append the lanes with `pass` (entry: leaf index, group parity, lane that owns the ray, the ray); runs a chunk as soon
+// Append the lanes with `pass` (entry: leaf index, group parity, lane that owns the ray); runs a chunk as soon
 // as 64 entries are pending.  Wave-uniform control flow.
-PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner, int lane, f3 o, f3 d,
+PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner, int lane,
                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const unsigned long long m = __ballot(pass);
   if (!m) return;
@@ -958,8 +959,6 @@ PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner,
   if (pass) {
     const int idx = (c.head + c.count + rank) & (kRing - 1);
     c.ent[idx] = (leaf << 7) | ((uint32_t)par << 6) | (uint32_t)owner;
-    c.ray[0 * kRing + idx] = o.x, c.ray[1 * kRing + idx] = o.y, c.ray[2 * kRing + idx] = o.z;
-    c.ray[3 * kRing + idx] = d.x, c.ray[4 * kRing + idx] = d.y, c.ray[5 * kRing + idx] = d.z;
   }
   const int cnt = __popcll(m);
   c.count += cnt;
@@ -971,6 +970,11 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
                          unsigned long long top_xor) {
   const RayInv ri = ray_inv(d);
+  {
+    float* ray = c.ray + par * 6 * 64 + lane;  // this group's rays, read back by the primitive-test chunks
+    ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
+    ray[3 * 64] = d.x, ray[4 * 64] = d.y, ray[5 * 64] = d.z;
+  }
   uint32_t pend = 0;  // per lane: top entries that are subtrees and whose box this ray passes
   float4 A = top[0], B = top[1];
   for (int e = 0; e < ntop; ++e) {
@@ -979,7 +983,7 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
     const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
     const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
-    if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, lane, o, d, nodes, geoms);
+    if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, lane, nodes, geoms);
     else if (pass) pend |= 1u << e;
   }
   // Subtrees below the cut (large scenes only).  Every lane walks its own ray's entered subtrees back to back
@@ -987,11 +991,11 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
   // (ray, subtree) pair from a lane that still has some — the loop count of the wave is what bounds this phase
   // (~60 VALU per step, lanes' totals range from 0 to several hundred node visits), so the goal is
   // steps ~ total visits / 64 rather than the maximum over the lanes.  A stolen pair is walked with the donor's
-  // ray (fetched with ds_bpermute) and its candidates are filed under the donor's lane, so nothing downstream
+  // ray origin and reciprocal direction (fetched with ds_bpermute) and its candidates are filed under the donor's lane, so nothing downstream
   // changes.  A lane only steals once its own list is empty, hence a donor's registers always hold its own ray.
   if (__ballot(pend != 0)) {
     int cur = 0, end = 0, own = lane;
-    f3 wo = o, wd = d;
+    f3 wo = o;
     RayInv wri = ri;
     const uint32_t xm = octant_mask(ri, top_xor);  // near-first order of this ray's subtrees (permute_xor)
     pend = permute_xor(pend, xm);
@@ -1018,7 +1022,6 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
           const uint32_t dpend = (uint32_t)__builtin_amdgcn_ds_bpermute(donor << 2, (int)pend);
           const int dxm = __builtin_amdgcn_ds_bpermute(donor << 2, (int)xm);
           const f3 so = mk(bperm(donor, wo.x), bperm(donor, wo.y), bperm(donor, wo.z));
-          const f3 sd = mk(bperm(donor, wd.x), bperm(donor, wd.y), bperm(donor, wd.z));
           const f3 si = mk(bperm(donor, wri.ix), bperm(donor, wri.iy), bperm(donor, wri.iz));
           if (pend != 0 && drank < ni) pend &= pend - 1;  // given away
           if (take) {
@@ -1027,7 +1030,7 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
             cur = __float_as_int(TB.z) + 1;
             end = __float_as_int(TB.w);
             own = donor;
-            wo = so, wd = sd;
+            wo = so;
             wri.ix = si.x, wri.iy = si.y, wri.iz = si.z;
             wri.sx = si.x < 0.0f, wri.sy = si.y < 0.0f, wri.sz = si.z < 0.0f;
           }
@@ -1038,7 +1041,7 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
       bool cand;
       int at_n, aux;
       scan_step(nodes, wo, wri, act, cur, bt, cand, at_n, aux);
-      carry_append(c, cand, (uint32_t)at_n, par, own, lane, wo, wd, nodes, geoms);
+      carry_append(c, cand, (uint32_t)at_n, par, own, lane, nodes, geoms);
     }
   }
 }
