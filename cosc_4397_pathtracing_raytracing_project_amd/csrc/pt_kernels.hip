@@ -64,6 +64,10 @@ PT_DEV f3 mulMV(const float* m, f3 v, float w) {
 }
 
 PT_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+// value of v in lane src_lane
+PT_DEV float bperm(int src_lane, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
 
 // Exact a / n and a % n for 0 <= a < 2^30 and quotients below 2^15 (sample ids / tile pixels,
 // pixel index / image width): float estimate + one correction step either way, ~10 VALU instead of
@@ -333,6 +337,47 @@ PT_DEV void scan_step(const ptd::Node* __restrict__ nodes, f3 o, const RayInv& r
   if (act) cur = in ? cur + 1 : __float_as_int(NB.z);
 }
 
+// State of a lane's subtree scan: the subtree range being scanned and the ray it is scanned for (the lane's own
+// ray, or a donor's after a steal — see steal_step).
+struct Walker {
+  int cur, end;  // next node / one past the subtree's last node (cur >= end: idle)
+  int own;       // lane that owns the ray (candidates are filed under it)
+  f3 o;          // ray origin
+  RayInv ri;     // reciprocal direction
+};
+// Work stealing inside the wave.  The scan loop runs max-over-lanes steps, and lanes' totals range from 0 to several
+// hundred node visits (rays enter 0-10 subtrees, a subtree costs 5-150 visits), so lanes whose own pending list
+// is empty take one pending (ray, subtree) pair each from lanes that still have some: donors publish their lane id
+// in `slot` (64 ints of LDS) by rank, the k-th idle lane reads the k-th donor's id, fetches its pending mask, XOR
+// mask, ray origin and reciprocal direction with ds_bpermute, and the donor drops the pair it gave away.
+// Called at wave-uniform control flow.  A lane only steals once its own list is empty, hence a donor's Walker
+// always holds the donor's own ray.  pend: pending subtrees in permute_xor order.
+PT_DEV void steal_step(Walker& w, uint32_t& pend, uint32_t xm, bool idle, unsigned long long I, int* slot,
+                       const float4* top, int lane) {
+  const unsigned long long Dn = __ballot(pend != 0);
+  if (!Dn) return;
+  const int nd = __popcll(Dn), ni = __popcll(I);
+  const int drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Dn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Dn, 0));
+  const int irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(I >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)I, 0));
+  if (pend != 0) slot[drank] = lane;  // the k-th donor's lane id
+  const bool take = idle && irank < nd;
+  const int donor = slot[take ? irank : 0];
+  const uint32_t dpend = (uint32_t)__builtin_amdgcn_ds_bpermute(donor << 2, (int)pend);
+  const int dxm = __builtin_amdgcn_ds_bpermute(donor << 2, (int)xm);
+  const f3 so = mk(bperm(donor, w.o.x), bperm(donor, w.o.y), bperm(donor, w.o.z));
+  const f3 si = mk(bperm(donor, w.ri.ix), bperm(donor, w.ri.iy), bperm(donor, w.ri.iz));
+  if (pend != 0 && drank < ni) pend &= pend - 1;  // given away
+  if (take) {
+    const int e = __builtin_ctz(dpend) ^ dxm;
+    const float4 TB = top[2 * e + 1];
+    w.cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
+    w.end = __float_as_int(TB.w);
+    w.own = donor;
+    w.o = so;
+    w.ri.ix = si.x, w.ri.iy = si.y, w.ri.iz = si.z;
+    w.ri.sx = si.x < 0.0f, w.ri.sy = si.y < 0.0f, w.ri.sz = si.z < 0.0f;
+  }
+}
 // Legacy traversal (kept for A/B measurements, PtOptions flag): one lane walks the threaded
 // tree and runs each primitive test as soon as the wave reaches it.
 PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const ptd::Geom* __restrict__ geoms, f3 o, f3 d) {
@@ -432,9 +477,6 @@ struct WaveLds {
 };
 constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;  // t_min = FLT_MAX
 
-PT_DEV float bperm(int src_lane, float v) {
-  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
 
 // Runs the pending candidates; called at wave-uniform control flow with all 64 lanes active.
 // One chunk of <= 64 candidates: `nc` cubes starting at list[cfirst] followed by `nsph` spheres starting at
@@ -521,61 +563,34 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       pend |= 1u << e;
     }
   }
-  // subtrees below the cut: every lane walks its entered subtrees back to back, independently of the others; lanes
-  // without work steal a pending (ray, subtree) pair from lanes that have several (see carry_search — same scheme;
-  // the donor table lives in the spare row of w.rec, candidates are filed under the owner's lane and the
-  // primitive tests fetch the ray from the owner's registers o, d as before)
+  // subtrees below the cut: every lane walks its entered subtrees back to back, independently of the others, nearest
+  // first; lanes without work steal pending (ray, subtree) pairs (steal_step; the donor table lives in the spare row
+  // of w.rec).  Candidates are filed under the owner's lane and the primitive tests fetch the ray from the owner's
+  // registers o, d as before.
   if (__ballot(pend != 0)) {
-    int cur = 0, end = 0, own = lane;
-    f3 wo = o;
-    RayInv wri = ri;
+    Walker wk{0, 0, lane, o, ri};
     int* slot = reinterpret_cast<int*>(w.rec + 6 * 64);
     const uint32_t xm = octant_mask(ri, top_xor);
     pend = permute_xor(pend, xm);
     while (true) {
-      if (cur >= end && pend) {
+      if (wk.cur >= wk.end && pend) {  // own subtrees first, nearest first
         const int e = __builtin_ctz(pend) ^ (int)xm;
         pend &= pend - 1;
         const float4 TB = top[2 * e + 1];
-        cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
-        end = __float_as_int(TB.w);
+        wk.cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
+        wk.end = __float_as_int(TB.w);
       }
-      const bool idle = cur >= end;
+      const bool idle = wk.cur >= wk.end;
       const unsigned long long I = __ballot(idle);
       if (I == ~0ull) break;
-      if (__popcll(I) >= kStealMin) {
-        const unsigned long long Dn = __ballot(pend != 0);
-        if (Dn) {
-          const int nd = __popcll(Dn), ni = __popcll(I);
-          const int drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Dn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Dn, 0));
-          const int irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(I >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)I, 0));
-          if (pend != 0) slot[drank] = lane;
-          const bool take = idle && irank < nd;
-          const int donor = slot[take ? irank : 0];
-          const uint32_t dpend = (uint32_t)__builtin_amdgcn_ds_bpermute(donor << 2, (int)pend);
-          const int dxm = __builtin_amdgcn_ds_bpermute(donor << 2, (int)xm);
-          const f3 so = mk(bperm(donor, wo.x), bperm(donor, wo.y), bperm(donor, wo.z));
-          const f3 si = mk(bperm(donor, wri.ix), bperm(donor, wri.iy), bperm(donor, wri.iz));
-          if (pend != 0 && drank < ni) pend &= pend - 1;  // given away
-          if (take) {
-            const int e = __builtin_ctz(dpend) ^ dxm;
-            const float4 TB = top[2 * e + 1];
-            cur = __float_as_int(TB.z) + 1;
-            end = __float_as_int(TB.w);
-            own = donor;
-            wo = so;
-            wri.ix = si.x, wri.iy = si.y, wri.iz = si.z;
-            wri.sx = si.x < 0.0f, wri.sy = si.y < 0.0f, wri.sz = si.z < 0.0f;
-          }
-        }
-      }
-      const bool act = cur < end;
+      if (__popcll(I) >= kStealMin) steal_step(wk, pend, xm, idle, I, slot, top, lane);
+      const bool act = wk.cur < wk.end;
       // closer-hit cull: a box entered beyond the ray's best hit so far (+ margin, see SceneTables::cull_margin)
       // cannot hold the closest hit
-      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * own + 1]) + cull;
+      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * wk.own + 1]) + cull;
       bool cand;
       int at_n, aux;
-      scan_step(nodes, wo, wri, act, cur, bt, cand, at_n, aux);
+      scan_step(nodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
       const bool cbox = cand && geoms[aux].type == 1;
       const bool csph = cand && !cbox;
       const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
@@ -584,7 +599,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
           flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
           nb = ns = 0;
         }
-        const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)own;
+        const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)wk.own;
         const int rb = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0));
         const int rs = __builtin_amdgcn_mbcnt_hi((uint32_t)(msp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msp, 0));
         const int cb = __popcll(mb), cs = __popcll(msp);
@@ -986,62 +1001,30 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
     if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, lane, nodes, geoms);
     else if (pass) pend |= 1u << e;
   }
-  // Subtrees below the cut (large scenes only).  Every lane walks its own ray's entered subtrees back to back
-  // with the stackless scan, independently of the other lanes; lanes that run out of work STEAL a pending
-  // (ray, subtree) pair from a lane that still has some — the loop count of the wave is what bounds this phase
-  // (~60 VALU per step, lanes' totals range from 0 to several hundred node visits), so the goal is
-  // steps ~ total visits / 64 rather than the maximum over the lanes.  A stolen pair is walked with the donor's
-  // ray origin and reciprocal direction (fetched with ds_bpermute) and its candidates are filed under the donor's lane, so nothing downstream
-  // changes.  A lane only steals once its own list is empty, hence a donor's registers always hold its own ray.
+  // Subtrees below the cut (large scenes only): per-lane stackless scans, nearest subtree first, with work stealing
+  // (scan_next / steal_step); candidates are filed under the lane that owns the ray, so nothing downstream changes.
   if (__ballot(pend != 0)) {
-    int cur = 0, end = 0, own = lane;
-    f3 wo = o;
-    RayInv wri = ri;
-    const uint32_t xm = octant_mask(ri, top_xor);  // near-first order of this ray's subtrees (permute_xor)
+    Walker wk{0, 0, lane, o, ri};
+    const uint32_t xm = octant_mask(ri, top_xor);
     pend = permute_xor(pend, xm);
     while (true) {
-      if (cur >= end && pend) {
+      if (wk.cur >= wk.end && pend) {  // own subtrees first, nearest first
         const int e = __builtin_ctz(pend) ^ (int)xm;
         pend &= pend - 1;
         const float4 TB = top[2 * e + 1];
-        cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
-        end = __float_as_int(TB.w);
+        wk.cur = __float_as_int(TB.z) + 1;  // the subtree root's box is the top entry's box: already passed
+        wk.end = __float_as_int(TB.w);
       }
-      const bool idle = cur >= end;
+      const bool idle = wk.cur >= wk.end;
       const unsigned long long I = __ballot(idle);
       if (I == ~0ull) break;
-      if (__popcll(I) >= kStealMin) {
-        const unsigned long long Dn = __ballot(pend != 0);
-        if (Dn) {
-          const int nd = __popcll(Dn), ni = __popcll(I);
-          const int drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Dn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Dn, 0));
-          const int irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(I >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)I, 0));
-          if (pend != 0) c.slot[drank] = lane;  // the k-th donor's lane id
-          const bool take = idle && irank < nd;
-          const int donor = c.slot[take ? irank : 0];
-          const uint32_t dpend = (uint32_t)__builtin_amdgcn_ds_bpermute(donor << 2, (int)pend);
-          const int dxm = __builtin_amdgcn_ds_bpermute(donor << 2, (int)xm);
-          const f3 so = mk(bperm(donor, wo.x), bperm(donor, wo.y), bperm(donor, wo.z));
-          const f3 si = mk(bperm(donor, wri.ix), bperm(donor, wri.iy), bperm(donor, wri.iz));
-          if (pend != 0 && drank < ni) pend &= pend - 1;  // given away
-          if (take) {
-            const int e = __builtin_ctz(dpend) ^ dxm;
-            const float4 TB = top[2 * e + 1];
-            cur = __float_as_int(TB.z) + 1;
-            end = __float_as_int(TB.w);
-            own = donor;
-            wo = so;
-            wri.ix = si.x, wri.iy = si.y, wri.iz = si.z;
-            wri.sx = si.x < 0.0f, wri.sy = si.y < 0.0f, wri.sz = si.z < 0.0f;
-          }
-        }
-      }
-      const bool act = cur < end;
-      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + own) + 1]) + cull;
+      if (__popcll(I) >= kStealMin) steal_step(wk, pend, xm, idle, I, c.slot, top, lane);
+      const bool act = wk.cur < wk.end;
+      const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + wk.own) + 1]) + cull;
       bool cand;
       int at_n, aux;
-      scan_step(nodes, wo, wri, act, cur, bt, cand, at_n, aux);
-      carry_append(c, cand, (uint32_t)at_n, par, own, lane, nodes, geoms);
+      scan_step(nodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
+      carry_append(c, cand, (uint32_t)at_n, par, wk.own, lane, nodes, geoms);
     }
   }
 }
