@@ -114,8 +114,17 @@ struct MinStd {
   // uniform_real_distribution<float>(0,1): float(x - 1) / 2^31 (exact scaling)
   PT_DEV float u01() { return (float)(next() - 1u) * 4.656612873077392578125e-10f; }
 };
-PT_DEV uint32_t seed_hash(int iter, int index, int depth) {  // pathtrace.cu:203-207
-  return utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter) ^ utilhash((uint32_t)index);
+// makeSeededRandomEngine (pathtrace.cu:203-207): seed = utilhash((1 << 31) | (depth << 22) | iter) ^ utilhash(index).
+// The first factor depends only on (iteration, depth): the kernels compute it once per iteration of the batch into
+// a small LDS table instead of once per ray (same values, ~18 VALU less per ray).
+PT_DEV uint32_t iter_hash(int iter, int depth) { return utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter); }
+constexpr int kIterHashMax = 256;  // table entries (iterations per batch it covers; larger batches hash per ray)
+PT_DEV void iter_hash_fill(uint32_t* tab, const BatchInfo& b, int depth) {  // before the kernel's __syncthreads()
+  if (b.K <= kIterHashMax)
+    for (int i = threadIdx.x; i < b.K; i += blockDim.x) tab[i] = iter_hash(b.iter_first + i, depth);
+}
+PT_DEV uint32_t iter_hash_of(const uint32_t* tab, const BatchInfo& b, int depth, int k) {
+  return b.K <= kIterHashMax ? tab[k] : iter_hash(b.iter_first + k, depth);
 }
 
 // ───────────────────────────── LDS staging ─────────────────────────────────
@@ -722,8 +731,8 @@ struct Bounce {
   int kind;         // 0 none, 1 specular, 2 diffuse
   float roughness;
 };
-PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, int iter, int pixel, float ht,
-                           int hmat, ShadeIO& s) {
+PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, uint32_t ihash, int pixel,
+                           float ht, int hmat, ShadeIO& s) {  // ihash = iter_hash(iteration, depth)
   Bounce bo;
   bo.kind = 0;
   bo.rng_x = 1u;
@@ -734,7 +743,7 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
     for (int k = depth; k < trace_depth; ++k) s.c = mul(s.c, sky);
     return bo;
   }
-  MinStd rng(seed_hash(iter, pixel, depth));
+  MinStd rng(ihash ^ utilhash((uint32_t)pixel));
   const ptd::Mat* m = mats + hmat;
   const f3 mcolor = mk(m->color[0], m->color[1], m->color[2]);
   if (m->emittance > 0.0f) {
@@ -843,6 +852,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
                                                   float* __restrict__ final_rgb) {
   extern __shared__ float4 lds_raw[];
   stage16(lds_raw, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_raw) + ((sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15));
+  iter_hash_fill(ihash, b, depth);
   __syncthreads();
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds_raw);
 
@@ -891,7 +902,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     if (valid) {
       int k, p;
       divmod(slot, b.N, inv_n, k, p);
-      bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, global_pixel(b, p), cur.ht, cur.hmat, s);
+      bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, b, depth, k), global_pixel(b, p), cur.ht, cur.hmat, s);
     }
     const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
@@ -1044,7 +1055,7 @@ struct Pending {
   bool any;  // wave-uniform: a group is pending
 };
 // Shading + retirement + compaction of a pending group from its resolved hit keys/records.
-PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __restrict__ mats,
+PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
                           const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
                           int depth, float inv_n, int64_t FS, float* __restrict__ final_rgb,
                           int32_t* __restrict__ counter, int64_t qbase, ptd::PathBuf out, int lane) {
@@ -1070,7 +1081,7 @@ PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __
     }
     int k, p;
     divmod(pg.slot, b.N, inv_n, k, p);
-    bo = shade_decide(mats, b.trace_depth, depth, b.iter_first + k, global_pixel(b, p), ht, hmat, s);
+    bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, b, depth, k), global_pixel(b, p), ht, hmat, s);
   }
   const Reservation res = retire_and_reserve(pg.valid, s, pg.slot, FS, final_rgb, counter, lane);
   const bool alive = pg.valid && s.alive;
@@ -1109,6 +1120,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
     tbl += nb_nodes + nb_geoms;
   }
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveLds);  // after the per-wave blocks
+  iter_hash_fill(ihash, b, 0);
   __syncthreads();
   const int wib = threadIdx.x >> 6;
   WaveLds w;
@@ -1172,7 +1185,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
         hn = mk(w.rec[0 * 64 + lane], w.rec[1 * 64 + lane], w.rec[2 * 64 + lane]);
         hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
       }
-      bo = shade_decide(mats, b.trace_depth, 0, b.iter_first + k, p, ht, hmat, s);
+      bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, b, 0, k), p, ht, hmat, s);
     }
     const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
@@ -1212,6 +1225,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
     tbl += nb_nodes + nb_geoms;
   }
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveLds2);  // after the per-wave blocks
+  iter_hash_fill(ihash, b, depth);
   __syncthreads();
   const int wib = threadIdx.x >> 6;
   Carry cy = carry_init(lds + tbl + wib * kWaveLds2);
@@ -1254,7 +1269,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     carry_search(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
     if (pg.any) {  // the previous group: all of its candidates are resolved once the ring has passed its mark
       carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-      shade_pending(cy, pg, mats, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
+      shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
     }
     pg.d = cur.d;
     pg.c = cur.c;
@@ -1266,7 +1281,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
   }
   if (pg.any) {
     carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-    shade_pending(cy, pg, mats, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
+    shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
   }
 }
 
@@ -1286,7 +1301,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trac
     s.d = mk(paths.d[at], paths.d[S + at], paths.d[2 * S + at]);
     s.c = mk(paths.c[at], paths.c[S + at], paths.c[2 * S + at]);
     s.alive = false;
-    const Bounce bo = shade_decide(mats, trace_depth, depth, iter[at], pixel[at], hits.t[at], hits.mat[at], s);
+    const Bounce bo = shade_decide(mats, trace_depth, depth, iter_hash(iter[at], depth), pixel[at], hits.t[at], hits.mat[at], s);
     // the stage reports the bounce ray whenever one is sampled (also at the last depth), like the reference
     if (bo.kind) shade_bounce(bo, mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]),
                               mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]), s);
@@ -1391,7 +1406,7 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2));
       break;
     case kShade:
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)));
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kIterHashMax * 4);
       break;
   }
   if (e != hipSuccess || n < 1) n = 1;
@@ -1418,7 +1433,8 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
 }
 
 static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds) {
-  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds;
+  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
+              kIterHashMax * 4;
   if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
   return bytes;
 }
@@ -1441,7 +1457,7 @@ void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchIn
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
                   float* final_rgb) {
-  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat));
+  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kIterHashMax * 4;
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
                      final_rgb);
 }

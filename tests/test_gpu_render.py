@@ -44,6 +44,7 @@ def gpu_render(scene_path, res, spp, depth=None, first=1, **kw):
     ("cornell", (200, 120), 7, 8, dict(num_queues=1, blocks_per_cu=1)),
     ("cornell", (200, 120), 7, 8, dict(num_queues=1024, blocks_per_cu=4)),
     ("cornell", (97, 61), 5, 1, {}),                                  # depth 1, odd sizes
+    ("cornell", (24, 16), 700, 8, dict(iters_per_batch=300)),        # > 256 iterations per batch: per-ray RNG hashing path
     ("sphere", (256, 256), 16, 4, {}),                                # BASELINE config C1
     ("stress", (160, 90), 6, 8, {}),
     ("stress", (160, 90), 6, 8, dict(legacy_traversal=True)),
