@@ -203,9 +203,11 @@ struct HitRec {
 // point / normal / distance are common to both types; only the middle (slab vs quadratic) differs.
 // TYPE: 1 cube (boxIntersectionTest, intersections.h:48-90), 0 sphere (sphereIntersectionTest,
 // intersections.h:102-144), -1 decided per lane from G->type.  Returns t (-1 = no hit).
-template <int TYPE>
-PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& point, f3& normal) {
-  const f3 qo = mulMV(G->inv, ro_w, 1.0f);
+// QO: the object-space origin is supplied by the caller (primary rays share the camera position, so it is one
+// value per geom: computed once per block by the primary kernel with this same mulMV).
+template <int TYPE, bool QO = false>
+PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& point, f3& normal, f3 qo_pre = f3{0.f, 0.f, 0.f}) {
+  const f3 qo = QO ? qo_pre : mulMV(G->inv, ro_w, 1.0f);
   const f3 qd = normalize(mulMV(G->inv, rd_w, 0.0f));
   const bool is_box = TYPE < 0 ? (G->type == 1) : (TYPE == 1);
   float t;
@@ -296,6 +298,18 @@ PT_DEV bool slab(f3 o, const RayInv& ri, float lox, float loy, float loz, float 
   return !(tmax <= tmin);
 }
 
+// slab() on a box given relative to the ray origin (lo - o, hi - o precomputed with the same subtraction).
+PT_DEV bool slab_rel(const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+  const float t0x = (ri.sx ? hix : lox) * ri.ix;
+  const float t1x = (ri.sx ? lox : hix) * ri.ix;
+  const float t0y = (ri.sy ? hiy : loy) * ri.iy;
+  const float t1y = (ri.sy ? loy : hiy) * ri.iy;
+  const float t0z = (ri.sz ? hiz : loz) * ri.iz;
+  const float t1z = (ri.sz ? loz : hiz) * ri.iz;
+  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
+  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
+  return !(tmax <= tmin);
+}
 // slab() that also returns the entry distance (for the closer-hit cull of the subtree scans).
 PT_DEV bool slab_t(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn) {
   const float t0x = ((ri.sx ? hix : lox) - o.x) * ri.ix;
@@ -492,18 +506,23 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 // list[sfirst].  TYPE 1 / 0: the chunk holds only cubes / only spheres (specialised code); TYPE -1: both —
 // the object-space transform of the ray and the world-space reconstruction are executed once for all
 // lanes and only the slab / quadratic middle parts diverge (geom_test<-1>).
-template <int TYPE>
+// CAM (primary kernel, tables in LDS): every ray starts at the camera, so the origin needs no fetch and its
+// object-space image comes from the per-geom table qo_tab.
+template <int TYPE, bool CAM>
 PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph, int lane, f3 o, f3 d,
-                      const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+                      const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab) {
   const bool valid = lane < nc + nsph;
   const uint32_t entry = valid ? w.list[lane < nc ? cfirst + lane : sfirst + (lane - nc)] : (uint32_t)lane;
   const int src = (int)(entry & 63u);
   const uint32_t leaf = entry >> 6;
-  const f3 ro = mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
+  const f3 ro = CAM ? o : mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
   const f3 rd = mk(bperm(src, d.x), bperm(src, d.y), bperm(src, d.z));
-  const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
+  const int gi = valid ? nodes[leaf].geom : 0;
+  const ptd::Geom* G = geoms + gi;
   f3 pt, nrm;
-  const float t = geom_test<TYPE>(G, ro, rd, pt, nrm);
+  float t;
+  if (CAM) t = geom_test<TYPE, true>(G, ro, rd, pt, nrm, mk(qo_tab[3 * gi], qo_tab[3 * gi + 1], qo_tab[3 * gi + 2]));
+  else t = geom_test<TYPE>(G, ro, rd, pt, nrm);
   const uint32_t tb = __float_as_uint(t);
   if (valid && t > 0.f && tb < 0x7f7fffffu) {
     const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
@@ -518,25 +537,29 @@ PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph
 // Chunk plan (a typical group at depth >= 1 holds ~55 cubes and ~12 spheres): full chunks of cubes,
 // then the remaining cubes together with the spheres in ONE mixed chunk if they fit in 64 lanes
 // (costs ~1.3x a pure chunk instead of two pure chunks), otherwise separately.
+template <bool CAM>
 PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
-                             const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+                             const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab) {
   const int sbase = kCandCap - ns;
   int c0 = 0;
-  for (; c0 + 64 <= nb; c0 += 64) run_chunk<1>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms);
+  for (; c0 + 64 <= nb; c0 += 64) run_chunk<1, CAM>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms, qo_tab);
   const int rem = nb - c0;
   if (rem > 0 && ns > 0 && rem + ns <= 64) {
-    run_chunk<-1>(w, c0, rem, sbase, ns, lane, o, d, nodes, geoms);
+    run_chunk<-1, CAM>(w, c0, rem, sbase, ns, lane, o, d, nodes, geoms, qo_tab);
     return;
   }
-  if (rem > 0) run_chunk<1>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms);
-  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms);
+  if (rem > 0) run_chunk<1, CAM>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms, qo_tab);
+  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0, CAM>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
 }
 
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
 // w.best[lane] holds the lane's (t bits << 32 | leaf) key (kNoHit if none) and w.rec its normal/point.
+// CAM: primary rays — `top` holds the entries' boxes relative to the camera position (slab_rel) and qo_tab the
+// camera position in every geom's object space (run_chunk<.., true>).
+template <bool CAM>
 PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull,
-                        unsigned long long top_xor) {
+                        unsigned long long top_xor, const float* qo_tab = nullptr) {
   const RayInv ri = ray_inv(d);
   w.best[lane] = kNoHit;
   int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
@@ -549,12 +572,12 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
     if (e + 1 < ntop) A = top[2 * e + 2], B = top[2 * e + 3];
     const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
-    const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
+    const bool pass = valid && (CAM ? slab_rel(ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y) : slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y));
     if (t_link < 0) {  // leaf entry: type is wave-uniform
       const unsigned long long m = __ballot(pass);
       if (m) {
         if (nb + ns + 64 > kCandCap) {
-          flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+          flush_candidates<CAM>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
           nb = ns = 0;
         }
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -605,7 +628,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
       if (mb | msp) {
         if (nb + ns + 128 > kCandCap) {
-          flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+          flush_candidates<CAM>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
           nb = ns = 0;
         }
         const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)wk.own;
@@ -619,7 +642,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       }
     }
   }
-  if (nb + ns) flush_candidates(w, nb, ns, lane, o, d, nodes, geoms);
+  if (nb + ns) flush_candidates<CAM>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
 }
 
 template <bool TABLES_IN_LDS>
@@ -682,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
       no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
       nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
     }
-    trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
+    trace_group<false>(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
 
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1122,6 +1145,22 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
   }
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveLds);  // after the per-wave blocks
   iter_hash_fill(ihash, b, 0);
+  // camera-relative copies for the primary rays (tables in LDS only): top-list boxes minus the camera position, and
+  // the camera position in each geom's object space — the same float operations the per-ray code would execute
+  float4* cam_top = reinterpret_cast<float4*>(ihash + kIterHashMax);
+  float* cam_qo = reinterpret_cast<float*>(cam_top + 2 * sc.num_top);
+  if (TABLES_IN_LDS) {
+    const f3 cp = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+    for (int e = threadIdx.x; e < sc.num_top; e += blockDim.x) {
+      const ptd::TopEntry t = sc.top[e];
+      cam_top[2 * e] = make_float4(t.bmin[0] - cp.x, t.bmin[1] - cp.y, t.bmin[2] - cp.z, t.bmax[0] - cp.x);
+      cam_top[2 * e + 1] = make_float4(t.bmax[1] - cp.y, t.bmax[2] - cp.z, __int_as_float(t.idx), __int_as_float(t.link));
+    }
+    for (int gi = threadIdx.x; gi < sc.num_geoms; gi += blockDim.x) {
+      const f3 q = mulMV(sc.geoms[gi].inv, cp, 1.0f);
+      cam_qo[3 * gi] = q.x, cam_qo[3 * gi + 1] = q.y, cam_qo[3 * gi + 2] = q.z;
+    }
+  }
   __syncthreads();
   const int wib = threadIdx.x >> 6;
   WaveLds w;
@@ -1164,7 +1203,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
     const bool near_scene = __ballot(valid && slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (near_scene) trace_group(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
+    if (near_scene) trace_group<TABLES_IN_LDS>(w, TABLES_IN_LDS ? cam_top : top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
     else w.best[lane] = kNoHit;
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1378,7 +1417,7 @@ inline int round16(int x) { return (x + 15) & ~15; }
 }  // namespace
 
 // ───────────────────────────── launch wrappers ─────────────────────────────
-static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds);
+static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false);
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
   int n = 0;
   hipError_t e = hipSuccess;
@@ -1398,7 +1437,7 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false>, kBlock, 0);
       break;
     case kPrimary:
-      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds));
+      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds));
       break;
     case kBounce:
@@ -1432,17 +1471,18 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
   else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), wave_lds, s, sc, qs, cnt_in, paths, hits);
 }
 
-static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds) {
+static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary) {
   int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
               kIterHashMax * 4;
   if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
+  if (in_lds && primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_geoms * 12);  // camera-relative copies
   return bytes;
 }
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                     const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float* final_rgb) {
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
   const bool in_lds = bytes <= kLdsTableBytes;
-  if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
+  if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
 }
 
