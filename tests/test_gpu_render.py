@@ -227,10 +227,10 @@ def test_preview_and_png(scene_dir, tmp_path):
 
 
 @pytest.mark.parametrize("name,spp", [("cornell", 6), ("sphere", 8)])
-def test_reference_scene_files_render_bit_exact(oracle, name, spp):
-    """The reference's own scene files (tests/golden/scenes, verbatim data) at their own resolution and depth."""
-    path = os.path.join(HERE, "golden", "scenes", name + ".txt")
+def test_scene_files_at_their_own_settings_bit_exact(oracle, scene_dir, name, spp):
+    """cornell.txt / sphere.txt exactly as written (their own resolution, depth and camera), full frame."""
     from cosc_4397_pathtracing_raytracing_project_amd import capi
+    path = scene_dir[name]
     sc = capi.Scene(path)
     w, h = sc.resolution
     r = capi.Renderer(sc)
