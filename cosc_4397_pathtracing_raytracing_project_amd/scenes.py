@@ -135,6 +135,45 @@ def stress_scene_text(grid: Tuple[int, int, int] = (22, 22, 21), res: Tuple[int,
     return "".join(out)
 
 
+def random_scene_text(seed: int, n_objects: int, res: Tuple[int, int] = (96, 64), iterations: int = 16, depth: int = 8,
+                      clustered: bool = False, name: str = "random") -> str:
+    """Fuzz input for the parity tests: `n_objects` cubes / spheres with random translation, rotation about all three
+    axes and NON-uniform scale inside (and poking through) the cornell box, random materials out of six (diffuse,
+    mirror, partly reflective with / without the refractive flag, two emitters).  `clustered` puts 80 % of the
+    objects into one corner so that the median-split BVH and its flattened top become unbalanced in extent.
+    Plain python `random` (Mersenne twister) so that the text is identical on every machine."""
+    import random
+    rnd = random.Random(seed)
+    mats = [
+        dict(rgb=(1, 1, 1), emittance=2),
+        dict(rgb=(".9", ".8", ".7")),
+        dict(rgb=(".2", ".7", ".9")),
+        dict(rgb=(".95", ".95", ".95"), specrgb=(".9", ".9", ".9"), refl=1),
+        dict(rgb=(".8", ".3", ".3"), specrgb=(".7", ".7", ".2"), refl=".4"),
+        dict(rgb=(".3", ".8", ".3"), specrgb=(".9", ".9", ".9"), refl=".6", refr=".5", refrior="1.5"),
+        dict(rgb=(1, ".6", ".2"), emittance=".7"),
+    ]
+    out: List[str] = [_material(i, **m) for i, m in enumerate(mats)]
+    out.append(_camera(res, 45, iterations, depth, name, ("0.0", 5, "10.5"), (0, 5, 0), (0, 1, 0)))
+    idx = 0
+    for kind, mat, t, r, sc in _CORNELL_OBJECTS[:6]:
+        out.append(_object(idx, kind, min(mat, 2), t, r, sc))
+        idx += 1
+    for k in range(n_objects):
+        if clustered and rnd.random() < 0.8:
+            t = (rnd.uniform(2.5, 4.8), rnd.uniform(0.2, 2.5), rnd.uniform(-4.8, -2.5))
+            smax = 0.5
+        else:
+            t = (rnd.uniform(-5.5, 5.5), rnd.uniform(-0.5, 10.5), rnd.uniform(-5.5, 4.0))
+            smax = 2.5 if n_objects < 100 else 0.8
+        r = tuple(round(rnd.uniform(0, 360), 2) for _ in range(3))
+        sc = tuple(round(rnd.uniform(0.05, smax), 3) for _ in range(3))
+        kind = "cube" if rnd.random() < 0.5 else "sphere"
+        out.append(_object(idx, kind, rnd.randrange(len(mats)), tuple(round(v, 3) for v in t), r, sc))
+        idx += 1
+    return "".join(out)
+
+
 def write_scene(text: str, path: str) -> str:
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
