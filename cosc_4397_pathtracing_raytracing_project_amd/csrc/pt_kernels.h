@@ -8,7 +8,7 @@ namespace ptk {
 
 constexpr int kBlock = 256;        // 4 wave64 per workgroup
 constexpr int kWavesPerBlock = 4;
-constexpr int kLdsTableBytes = 64 * 1024;  // scene tables are staged in LDS up to this size
+constexpr int kLdsTableBytes = 64 * 1024;  // upper limit for staging the scene tables in LDS (see auto_lds_table_limit)
 constexpr int kMaxTop = 32;                // entries in the flattened BVH top (per-lane 32-bit subtree mask)
 constexpr int kCandCap = 192;              // per-wave candidate list entries (LDS)
 constexpr int kWaveLds = 64 * 8 + 7 * 64 * 4 + kCandCap * 4;  // best keys + winner records + list = 3072 B
@@ -79,6 +79,10 @@ void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb
 // so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
 // a workgroup that has to wait for a free slot would run its whole share after everybody else.
 enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kBounce = 5 };
+// Scene tables (nodes + geoms) up to this many bytes are staged in LDS by the traversal kernels (default kLdsTableBytes).
+void set_lds_table_limit(int bytes);
+// ... or, by default, exactly when staging them costs the bounce kernel no resident block per CU.
+void auto_lds_table_limit(const SceneTables& sc);
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc);
 
 // Stage helper for tests: one shading step on n explicit paths (single queue, no compaction):

@@ -1418,6 +1418,23 @@ inline int round16(int x) { return (x + 15) & ~15; }
 
 // ───────────────────────────── launch wrappers ─────────────────────────────
 static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false);
+static int g_lds_table_bytes = kLdsTableBytes;
+void set_lds_table_limit(int bytes) { g_lds_table_bytes = bytes < 0 ? kLdsTableBytes : bytes; }
+// Stage the scene tables in LDS only if that does not cost the dominant kernel a resident block per CU: measured on
+// random scenes at 1080p, 156 geoms (52 KB of tables, 1 block/CU) ran at 2.2 Gsamples/s from LDS and 4.5 from
+// global memory / L2 (4 blocks/CU); 26 geoms (8 KB) are equal either way; cornell's 2.3 KB keep all 4 blocks.
+void auto_lds_table_limit(const SceneTables& sc) {
+  const int tbl = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
+  int with = 0, without = 0;
+  if (tbl <= kLdsTableBytes &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2)) != hipSuccess)
+    with = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2)) != hipSuccess)
+    without = 1;
+  (void)hipGetLastError();
+  g_lds_table_bytes = (with >= without && with > 0) ? tbl : -1;
+}
+
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
   int n = 0;
   hipError_t e = hipSuccess;
@@ -1427,21 +1444,21 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_generate, kBlock, 0);
       break;
     case kIntersect:
-      if (tbl <= kLdsTableBytes)
+      if (tbl <= g_lds_table_bytes)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true>, kBlock, round16(tbl) + kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
       else
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false>, kBlock, kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
       break;
     case kIntersectLegacy:
-      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true>, kBlock, round16(tbl));
+      if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true>, kBlock, round16(tbl));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false>, kBlock, 0);
       break;
     case kPrimary:
-      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
+      if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds));
       break;
     case kBounce:
-      if (tbl <= kLdsTableBytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2));
+      if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2));
       break;
     case kShade:
@@ -1460,7 +1477,7 @@ void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const Batc
 void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
                       ptd::PathBuf paths, ptd::HitBuf hits, bool legacy) {
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
-  const bool in_lds = bytes <= kLdsTableBytes;
+  const bool in_lds = bytes <= g_lds_table_bytes;
   if (legacy) {
     if (in_lds) hipLaunchKernelGGL(k_intersect_legacy<true>, dim3(grid), dim3(kBlock), round16(bytes), s, sc, qs, cnt_in, paths, hits);
     else hipLaunchKernelGGL(k_intersect_legacy<false>, dim3(grid), dim3(kBlock), 0, s, sc, qs, cnt_in, paths, hits);
@@ -1481,7 +1498,7 @@ static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, boo
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                     const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float* final_rgb) {
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
-  const bool in_lds = bytes <= kLdsTableBytes;
+  const bool in_lds = bytes <= g_lds_table_bytes;
   if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
 }
@@ -1489,7 +1506,7 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                    const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float* final_rgb) {
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
-  const bool in_lds = bytes <= kLdsTableBytes;
+  const bool in_lds = bytes <= g_lds_table_bytes;
   if (in_lds) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
   else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
 }

@@ -72,6 +72,19 @@ def test_image_bit_exact_vs_oracle(scene_dir, oracle, scene, res, spp, depth, kw
     assert st.samples == res[0] * res[1] * spp
 
 
+@pytest.mark.parametrize("kw", [{}, dict(unfused_bounces=True), dict(unfused_primary=True)])
+def test_forced_lds_tables_with_subtrees(scene_dir, oracle, monkeypatch, kw):
+    """By default scene tables are staged in LDS only while that keeps every resident block (a few KB: cornell); the
+    kernels' LDS-table variants also handle scenes with real subtrees — force them with PT_LDS_TABLE_KB."""
+    monkeypatch.setenv("PT_LDS_TABLE_KB", "64")
+    img, _ = gpu_render(scene_dir["stress"], (160, 90), 5, 8, **kw)
+    monkeypatch.delenv("PT_LDS_TABLE_KB")
+    oracle.set_math_mode(oracle.PORTABLE)
+    oracle.load_scene(scene_dir["stress"], res=(160, 90))
+    ref = oracle.render(1, 5, depth=8, variant=oracle.RETIRE, nthreads=16)
+    assert np.array_equal(bits(img), bits(ref))
+
+
 def test_image_vs_reference_semantics_tolerance(scene_dir, oracle):
     """Against the LIBM-mode oracle (the reference's own arithmetic, pinned by the survey KATs).
     Stated tolerance (SURVEY §8c): no NaN/Inf; >= 99.8 % of pixels within 1e-5 at <= 16 spp;
