@@ -567,7 +567,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   {
     const ptk::SceneTables t = tables();
     const char* kb = getenv("PT_LDS_TABLE_KB");  // test / experiment knob: force the LDS staging limit of the scene tables
-    if (kb) ptk::set_lds_table_limit(atoi(kb) * 1024);
+    if (kb) ptk::set_lds_table_limit(t, atoi(kb) * 1024);
     else ptk::auto_lds_table_limit(t);
     const int cap_bpc = opt.blocks_per_cu > 0 ? std::min(opt.blocks_per_cu, 8) : 8;
     g.grid_gen = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kGenerate, t));

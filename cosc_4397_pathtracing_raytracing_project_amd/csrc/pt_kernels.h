@@ -79,8 +79,9 @@ void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb
 // so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
 // a workgroup that has to wait for a free slot would run its whole share after everybody else.
 enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kBounce = 5 };
-// Scene tables (nodes + geoms) up to this many bytes are staged in LDS by the traversal kernels (default kLdsTableBytes).
-void set_lds_table_limit(int bytes);
+// Scene tables (nodes + geoms) up to this many bytes are staged in LDS by the traversal kernels (only scenes whose
+// leaves all fit the top list; test / experiment knob) ...
+void set_lds_table_limit(const SceneTables& sc, int bytes);
 // ... or, by default, exactly when staging them costs the bounce kernel no resident block per CU.
 void auto_lds_table_limit(const SceneTables& sc);
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc);

@@ -1015,6 +1015,9 @@ PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner,
   if (c.count >= 64) carry_chunk(c, 64, lane, nodes, geoms);
 }
 // Candidate search of one group (phase 1 of trace_group) feeding the ring.
+// SUB: the scene has subtrees below the top list.  The LDS-table kernels are only used for scenes whose leaves all
+// fit the top list (auto_lds_table_limit), so their instantiation drops the subtree scan.
+template <bool SUB>
 PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
                          unsigned long long top_xor) {
@@ -1037,7 +1040,7 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
   }
   // Subtrees below the cut (large scenes only): per-lane stackless scans, nearest subtree first, with work stealing
   // (scan_next / steal_step); candidates are filed under the lane that owns the ray, so nothing downstream changes.
-  if (__ballot(pend != 0)) {
+  if (SUB && __ballot(pend != 0)) {
     Walker wk{0, 0, lane, o, ri};
     const uint32_t xm = octant_mask(ri, top_xor);
     pend = permute_xor(pend, xm);
@@ -1305,7 +1308,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is searched
     const int par = it & 1;
     cy.best[par * 64 + lane] = kNoHit;
-    carry_search(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
+    carry_search<!TABLES_IN_LDS>(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
     if (pg.any) {  // the previous group: all of its candidates are resolved once the ring has passed its mark
       carry_drain_to(cy, pg.mark, lane, nodes, geoms);
       shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
@@ -1419,14 +1422,17 @@ inline int round16(int x) { return (x + 15) & ~15; }
 // ───────────────────────────── launch wrappers ─────────────────────────────
 static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false);
 static int g_lds_table_bytes = kLdsTableBytes;
-void set_lds_table_limit(int bytes) { g_lds_table_bytes = bytes < 0 ? kLdsTableBytes : bytes; }
-// Stage the scene tables in LDS only if that does not cost the dominant kernel a resident block per CU: measured on
+// The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
+static bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
+void set_lds_table_limit(const SceneTables& sc, int bytes) { g_lds_table_bytes = leaves_fit_top(sc) ? bytes : -1; }
+// Stage the scene tables in LDS only if every leaf is a top-list entry and staging does not cost the dominant kernel a
+// resident block per CU: measured on
 // random scenes at 1080p, 156 geoms (52 KB of tables, 1 block/CU) ran at 2.2 Gsamples/s from LDS and 4.5 from
 // global memory / L2 (4 blocks/CU); 26 geoms (8 KB) are equal either way; cornell's 2.3 KB keep all 4 blocks.
 void auto_lds_table_limit(const SceneTables& sc) {
   const int tbl = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
   int with = 0, without = 0;
-  if (tbl <= kLdsTableBytes &&
+  if (tbl <= kLdsTableBytes && leaves_fit_top(sc) &&
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2)) != hipSuccess)
     with = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2)) != hipSuccess)
