@@ -88,10 +88,12 @@ typedef struct PtOptions {
   int32_t time_kernels;    /* 1: bracket every computeIntersections launch with  */
                            /*    HIP events on the render stream (pt_get_stats)  */
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
-  int32_t debug_flags;      /* profiling only, results are WRONG: bit0 intersect skips tracing (memory-side
-                               floor of the kernel), bit1 shade skips shading (every path retires); bit4 (16) only disables
-                               the closer-hit cull of the subtree scans, bit5 (32) only disables their near-first
-                               subtree order (results unchanged; A/B) */
+  int32_t debug_flags;      /* profiling / A-B switches.  Results are WRONG with bits 0-3: 1 intersect skips tracing
+                               (memory-side floor of the kernel), 2 shade skips shading (every path retires),
+                               4 skip the primitive tests, 8 skip the bounce-direction sampling.  Results are
+                               UNCHANGED with bits 4-5: 16 no closer-hit cull in the subtree scans, 32 no
+                               near-first subtree order.  (Environment, tests only: PT_LDS_TABLE_KB forces the
+                               LDS staging limit of the scene tables.) */
   int32_t unfused_primary;  /* 1: run depth 0 as generate + intersect + shade launches instead of the fused
                                primary kernel (A/B and stage-parity runs) */
   int32_t unfused_bounces;  /* 1: depths >= 1 as separate computeIntersections + shade launches (hit records
