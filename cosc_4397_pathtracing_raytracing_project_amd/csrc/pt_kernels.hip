@@ -1206,9 +1206,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     int px, py;
     divmod(p, cam.res_x, inv_w, py, px);
     // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene.  The
-    // primary ray of a pixel is the same for all K iterations of the batch, so is its test against the bounds of the
-    // whole tree: k_root_spans (launched by every batch just before this kernel, same camera_dir / slab code)
-    // evaluates it once per pixel and keeps, per image row, the span of columns that pass.  Outside the span a ray fails the root box, hence every box below it (the slab
+    // primary ray of a pixel is the same in every iteration, so is its test against the bounds of the whole tree:
+    // k_root_spans evaluated it once per pixel at init (same camera_dir / slab code) and kept, per image row, the
+    // span of columns that pass.  Outside the span a ray fails the root box, hence every box below it (the slab
     // arithmetic is monotone): such lanes have no hit, and bundles without any lane inside skip the search.
     const int2 span = sc.root_spans[py];
     const f3 d = camera_dir_xy(cam, px, py);
