@@ -65,7 +65,6 @@ struct Ctx {
   std::vector<void*> allocs;
   int64_t device_bytes = 0;
   ptd::Node* d_nodes = nullptr;
-  int2* d_spans = nullptr;  // SceneTables::root_spans
   ptd::Geom* d_geoms = nullptr;
   ptd::Mat* d_mats = nullptr;
   ptd::TopEntry* d_top = nullptr;
@@ -253,7 +252,6 @@ ptk::SceneTables tables() {
   t.num_top = (g.debug_flags & 1) ? 0 : g.num_top;
   std::memcpy(t.root_min, g.root_min, 12);
   std::memcpy(t.root_max, g.root_max, 12);
-  t.root_spans = g.d_spans;
   t.cull_margin = (g.debug_flags & 16) ? INFINITY : g.cull_margin;
   t.top_xor = (g.debug_flags & 32) ? 0ull : g.top_xor;
   return t;
@@ -565,9 +563,6 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
-  if (dalloc(&g.d_spans, (size_t)H)) return -1;
-  ptk::launch_root_spans(g.stream, tables(), g.dcam, g.d_spans);
-  HIP_OK(hipGetLastError());
 
   {
     const ptk::SceneTables t = tables();

@@ -25,7 +25,6 @@ struct SceneTables {
   const ptd::TopEntry* top;  // flattened BVH top (see ptd::TopEntry)
   int32_t num_top;
   float root_min[3], root_max[3];  // bounds of the whole tree (reference node 0)
-  const int2* root_spans;          // per image row: columns whose primary ray passes those bounds (k_root_spans)
   // Closer-hit cull of the subtree scans: a box whose entry distance exceeds the ray's best hit distance so far
   // by more than this margin cannot contain the closest hit.  The reported hit distance is measured to a point
   // pulled 1e-4 object units towards the ray origin (intersections.h:27-29) and carries the rounding of two
@@ -71,7 +70,6 @@ void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInf
 // finalGather: image[p] += final[0][p] + final[1][p] + ... in iteration order.
 void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, float* image_rgb /* [N][3] */);
 // live-ray bookkeeping: stats[d] += sum_q cnt[d][q]
-void launch_root_spans(hipStream_t s, const SceneTables& sc, const ptd::Camera& cam, int2* spans);
 void launch_count_stats(hipStream_t s, const ptd::Queues& qs, const int32_t* cnt, int depth_count,
                         unsigned long long* stats);
 // sendImageToPBO (pathtrace.cu:250-268)

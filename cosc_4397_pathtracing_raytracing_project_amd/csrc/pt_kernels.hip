@@ -146,18 +146,15 @@ PT_DEV int global_pixel(const BatchInfo& b, int p) {
 // ───────────────────────────── generate ────────────────────────────────────
 // generateRayFromCamera (pathtrace.cu:270-286) for global pixel index p:
 // dir = normalize(view - right*pl.x*(x - W/2) - up*pl.y*(y - H/2)); no jitter, `iter` unused.
-PT_DEV f3 camera_dir_xy(const ptd::Camera& cam, int x, int y) {
+PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p) {
+  int x, y;
+  divmod(p, cam.res_x, inv_w, y, x);
   const float fx = (float)x - cam.res_x * 0.5f;
   const float fy = (float)y - cam.res_y * 0.5f;
   const f3 view = mk(cam.view[0], cam.view[1], cam.view[2]);
   const f3 a = scl(scl(mk(cam.right[0], cam.right[1], cam.right[2]), cam.pl_x), fx);
   const f3 c = scl(scl(mk(cam.up[0], cam.up[1], cam.up[2]), cam.pl_y), fy);
   return normalize(sub(sub(view, a), c));
-}
-PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p) {
-  int x, y;
-  divmod(p, cam.res_x, inv_w, y, x);
-  return camera_dir_xy(cam, x, y);
 }
 
 __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo b, ptd::Queues qs, ptd::PathBuf out,
@@ -1203,18 +1200,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     int k, pl;
     divmod(slot, b.N, inv_n, k, pl);
     const int p = global_pixel(b, pl);  // global pixel index
-    int px, py;
-    divmod(p, cam.res_x, inv_w, py, px);
-    // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene.  The
-    // primary ray of a pixel is the same in every iteration, so is its test against the bounds of the whole tree:
-    // k_root_spans evaluated it once per pixel at init (same camera_dir / slab code) and kept, per image row, the
-    // span of columns that pass.  Outside the span a ray fails the root box, hence every box below it (the slab
-    // arithmetic is monotone): such lanes have no hit, and bundles without any lane inside skip the search.
-    const int2 span = sc.root_spans[py];
-    const f3 d = camera_dir_xy(cam, px, py);
-    const bool in_span = valid && px >= span.x && px <= span.y;
-    const bool near_scene = __ballot(in_span) != 0;
-    if (near_scene) trace_group<TABLES_IN_LDS>(w, TABLES_IN_LDS ? cam_top : top, ntop, nodes, geoms, o, d, in_span, lane, sc.cull_margin, sc.top_xor, cam_qo);
+    const f3 d = camera_dir(cam, inv_w, p);
+    // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
+    // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
+    // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
+    const bool near_scene = __ballot(valid && slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+                                                   sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
+    if (near_scene) trace_group<TABLES_IN_LDS>(w, TABLES_IN_LDS ? cam_top : top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
     else w.best[lane] = kNoHit;
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1391,28 +1383,6 @@ __global__ __launch_bounds__(kBlock) void k_gather(BatchInfo b, const float* __r
   }
 }
 
-// Per image row, the span [lo, hi] of columns whose primary ray passes the bounds of the whole tree (lo > hi: none);
-// see k_primary.  One block per row.
-__global__ __launch_bounds__(kBlock) void k_root_spans(SceneTables sc, ptd::Camera cam, int2* __restrict__ spans) {
-  __shared__ int lo, hi;
-  const int y = blockIdx.x;
-  if (threadIdx.x == 0) lo = cam.res_x, hi = -1;
-  __syncthreads();
-  const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
-  int mylo = cam.res_x, myhi = -1;
-  for (int x = threadIdx.x; x < cam.res_x; x += blockDim.x) {
-    const f3 d = camera_dir_xy(cam, x, y);
-    if (slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2], sc.root_max[0], sc.root_max[1], sc.root_max[2])) {
-      mylo = min(mylo, x);
-      myhi = max(myhi, x);
-    }
-  }
-  atomicMin(&lo, mylo);
-  atomicMax(&hi, myhi);
-  __syncthreads();
-  if (threadIdx.x == 0) spans[y] = make_int2(lo, hi);
-}
-
 __global__ void k_count_stats(ptd::Queues qs, const int32_t* __restrict__ cnt, int depth_count,
                               unsigned long long* __restrict__ stats) {
   // one block per depth
@@ -1560,10 +1530,6 @@ void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, fl
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlock), 0, s, b, final_rgb, image_rgb);
-}
-
-void launch_root_spans(hipStream_t s, const SceneTables& sc, const ptd::Camera& cam, int2* spans) {
-  hipLaunchKernelGGL(k_root_spans, dim3(cam.res_y), dim3(kBlock), 0, s, sc, cam, spans);
 }
 
 void launch_count_stats(hipStream_t s, const ptd::Queues& qs, const int32_t* cnt, int depth_count,
