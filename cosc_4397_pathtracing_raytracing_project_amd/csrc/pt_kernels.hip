@@ -506,9 +506,9 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 // list[sfirst].  TYPE 1 / 0: the chunk holds only cubes / only spheres (specialised code); TYPE -1: both —
 // the object-space transform of the ray and the world-space reconstruction are executed once for all
 // lanes and only the slab / quadratic middle parts diverge (geom_test<-1>).
-// CAM (primary kernel, tables in LDS): every ray starts at the camera, so the origin needs no fetch and its
+// CAM (primary kernel): every ray starts at the camera, so the origin needs no fetch; QO (tables in LDS): its
 // object-space image comes from the per-geom table qo_tab.
-template <int TYPE, bool CAM>
+template <int TYPE, bool CAM, bool QO>
 PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph, int lane, f3 o, f3 d,
                       const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab) {
   const bool valid = lane < nc + nsph;
@@ -521,7 +521,7 @@ PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph
   const ptd::Geom* G = geoms + gi;
   f3 pt, nrm;
   float t;
-  if (CAM) t = geom_test<TYPE, true>(G, ro, rd, pt, nrm, mk(qo_tab[3 * gi], qo_tab[3 * gi + 1], qo_tab[3 * gi + 2]));
+  if (QO) t = geom_test<TYPE, true>(G, ro, rd, pt, nrm, mk(qo_tab[3 * gi], qo_tab[3 * gi + 1], qo_tab[3 * gi + 2]));
   else t = geom_test<TYPE>(G, ro, rd, pt, nrm);
   const uint32_t tb = __float_as_uint(t);
   if (valid && t > 0.f && tb < 0x7f7fffffu) {
@@ -537,26 +537,26 @@ PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph
 // Chunk plan (a typical group at depth >= 1 holds ~55 cubes and ~12 spheres): full chunks of cubes,
 // then the remaining cubes together with the spheres in ONE mixed chunk if they fit in 64 lanes
 // (costs ~1.3x a pure chunk instead of two pure chunks), otherwise separately.
-template <bool CAM>
+template <bool CAM, bool QO>
 PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
                              const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab) {
   const int sbase = kCandCap - ns;
   int c0 = 0;
-  for (; c0 + 64 <= nb; c0 += 64) run_chunk<1, CAM>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms, qo_tab);
+  for (; c0 + 64 <= nb; c0 += 64) run_chunk<1, CAM, QO>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms, qo_tab);
   const int rem = nb - c0;
   if (rem > 0 && ns > 0 && rem + ns <= 64) {
-    run_chunk<-1, CAM>(w, c0, rem, sbase, ns, lane, o, d, nodes, geoms, qo_tab);
+    run_chunk<-1, CAM, QO>(w, c0, rem, sbase, ns, lane, o, d, nodes, geoms, qo_tab);
     return;
   }
-  if (rem > 0) run_chunk<1, CAM>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms, qo_tab);
-  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0, CAM>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
+  if (rem > 0) run_chunk<1, CAM, QO>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms, qo_tab);
+  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0, CAM, QO>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
 }
 
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
 // w.best[lane] holds the lane's (t bits << 32 | leaf) key (kNoHit if none) and w.rec its normal/point.
 // CAM: primary rays — `top` holds the entries' boxes relative to the camera position (slab_rel) and qo_tab the
 // camera position in every geom's object space (run_chunk<.., true>).
-template <bool CAM>
+template <bool CAM, bool QO = CAM>
 PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull,
                         unsigned long long top_xor, const float* qo_tab = nullptr) {
@@ -577,7 +577,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const unsigned long long m = __ballot(pass);
       if (m) {
         if (nb + ns + 64 > kCandCap) {
-          flush_candidates<CAM>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+          flush_candidates<CAM, QO>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
           nb = ns = 0;
         }
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -628,7 +628,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
       if (mb | msp) {
         if (nb + ns + 128 > kCandCap) {
-          flush_candidates<CAM>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+          flush_candidates<CAM, QO>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
           nb = ns = 0;
         }
         const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)wk.own;
@@ -642,7 +642,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       }
     }
   }
-  if (nb + ns) flush_candidates<CAM>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+  if (nb + ns) flush_candidates<CAM, QO>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
 }
 
 template <bool TABLES_IN_LDS>
@@ -1148,18 +1148,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
   }
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveLds);  // after the per-wave blocks
   iter_hash_fill(ihash, b, 0);
-  // camera-relative copies for the primary rays (tables in LDS only): top-list boxes minus the camera position, and
+  // camera-relative copies for the primary rays: top-list boxes minus the camera position and (tables in LDS only)
   // the camera position in each geom's object space — the same float operations the per-ray code would execute
   float4* cam_top = reinterpret_cast<float4*>(ihash + kIterHashMax);
   float* cam_qo = reinterpret_cast<float*>(cam_top + 2 * sc.num_top);
-  if (TABLES_IN_LDS) {
+  {
     const f3 cp = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
     for (int e = threadIdx.x; e < sc.num_top; e += blockDim.x) {
       const ptd::TopEntry t = sc.top[e];
       cam_top[2 * e] = make_float4(t.bmin[0] - cp.x, t.bmin[1] - cp.y, t.bmin[2] - cp.z, t.bmax[0] - cp.x);
       cam_top[2 * e + 1] = make_float4(t.bmax[1] - cp.y, t.bmax[2] - cp.z, __int_as_float(t.idx), __int_as_float(t.link));
     }
-    for (int gi = threadIdx.x; gi < sc.num_geoms; gi += blockDim.x) {
+    for (int gi = threadIdx.x; TABLES_IN_LDS && gi < sc.num_geoms; gi += blockDim.x) {
       const f3 q = mulMV(sc.geoms[gi].inv, cp, 1.0f);
       cam_qo[3 * gi] = q.x, cam_qo[3 * gi + 1] = q.y, cam_qo[3 * gi + 2] = q.z;
     }
@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
     const bool near_scene = __ballot(valid && slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (near_scene) trace_group<TABLES_IN_LDS>(w, TABLES_IN_LDS ? cam_top : top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
+    if (near_scene) trace_group<true, TABLES_IN_LDS>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
     else w.best[lane] = kNoHit;
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1461,7 +1461,7 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       break;
     case kPrimary:
       if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kBounce:
       if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2));
@@ -1498,7 +1498,7 @@ static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, boo
   int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
               kIterHashMax * 4;
   if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
-  if (in_lds && primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_geoms * 12);  // camera-relative copies
+  if (primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + (in_lds ? round16(sc.num_geoms * 12) : 0);  // camera-relative copies
   return bytes;
 }
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
@@ -1506,7 +1506,7 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
   const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
   const bool in_lds = bytes <= g_lds_table_bytes;
   if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
 }
 
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
