@@ -292,8 +292,6 @@ int run_batch(int iter_first, int kb) {
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;
   b.inv_stripe = g.stripe ? 1.0f / (float)g.stripe : 0.0f;
-  const size_t cnt_ints = (size_t)(g.depth + 1) * g.qs.Q * g.qs.cnt_stride;
-  HIP_OK(hipMemsetAsync(g.d_cnt, 0, cnt_ints * sizeof(int32_t), g.stream));
   const ptk::SceneTables sc = tables();
   const size_t per_depth = (size_t)g.qs.Q * g.qs.cnt_stride;
   int d0 = 0;
@@ -581,6 +579,7 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   if (!g.fuse_bounces && alloc_hitbuf(&g.hits, g.stride)) return -1;  // hit records reach HBM only in the unfused form
   if (dalloc(&g.d_final, 3 * (size_t)total) || dalloc(&g.d_image, 3 * (size_t)g.N)) return -1;
   if (dalloc(&g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;
+  HIP_OK(hipMemset(g.d_cnt, 0, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride * sizeof(int32_t)));  // k_count_stats re-zeroes it after every batch
   if (dalloc(&g.d_stats, PT_MAX_DEPTH)) return -1;
   HIP_OK(hipMemset(g.d_image, 0, 3 * (size_t)g.N * sizeof(float)));
   HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));

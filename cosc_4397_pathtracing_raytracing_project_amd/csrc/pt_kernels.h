@@ -70,7 +70,7 @@ void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInf
 // finalGather: image[p] += final[0][p] + final[1][p] + ... in iteration order.
 void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, float* image_rgb /* [N][3] */);
 // live-ray bookkeeping: stats[d] += sum_q cnt[d][q]
-void launch_count_stats(hipStream_t s, const ptd::Queues& qs, const int32_t* cnt, int depth_count,
+void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count,
                         unsigned long long* stats);
 // sendImageToPBO (pathtrace.cu:250-268)
 void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba);

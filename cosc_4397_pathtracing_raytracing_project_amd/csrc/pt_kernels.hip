@@ -1383,13 +1383,19 @@ __global__ __launch_bounds__(kBlock) void k_gather(BatchInfo b, const float* __r
   }
 }
 
-__global__ void k_count_stats(ptd::Queues qs, const int32_t* __restrict__ cnt, int depth_count,
+__global__ void k_count_stats(ptd::Queues qs, int32_t* __restrict__ cnt, int depth_count,
                               unsigned long long* __restrict__ stats) {
-  // one block per depth
+  // one block per counter row (depth 0 .. depth_count): add the row's fill levels to the statistics and leave the
+  // row zeroed for the next batch (saves a memset launch per batch)
   const int d = blockIdx.x;
-  if (d >= depth_count) return;
+  if (d > depth_count) return;
   unsigned long long acc = 0;
-  for (int q = threadIdx.x; q < qs.Q; q += blockDim.x) acc += (unsigned long long)cnt[((size_t)d * qs.Q + q) * qs.cnt_stride];
+  for (int q = threadIdx.x; q < qs.Q; q += blockDim.x) {
+    int32_t* c = &cnt[((size_t)d * qs.Q + q) * qs.cnt_stride];
+    acc += (unsigned long long)*c;
+    *c = 0;
+  }
+  if (d == depth_count) return;  // the row behind the last depth only needs the reset
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   __shared__ unsigned long long part[kWavesPerBlock];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
@@ -1532,9 +1538,9 @@ void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, fl
   hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlock), 0, s, b, final_rgb, image_rgb);
 }
 
-void launch_count_stats(hipStream_t s, const ptd::Queues& qs, const int32_t* cnt, int depth_count,
+void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count,
                         unsigned long long* stats) {
-  hipLaunchKernelGGL(k_count_stats, dim3(depth_count), dim3(kBlock), 0, s, qs, cnt, depth_count, stats);
+  hipLaunchKernelGGL(k_count_stats, dim3(depth_count + 1), dim3(kBlock), 0, s, qs, cnt, depth_count, stats);
 }
 
 void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba) {
