@@ -78,7 +78,8 @@ def main() -> None:
     ap.add_argument("--unfused-primary", action="store_true", help="A/B: depth 0 as separate generate/intersect/shade launches")
     ap.add_argument("--contiguous-tiles", action="store_true", help="A/B: one block of rows per rank instead of interleaved rows")
     ap.add_argument("--unfused-bounces", action="store_true", help="A/B: depths >= 1 as separate intersect + shade launches")
-    ap.add_argument("--debug-flags", type=int, default=0, help="profiling only (wrong results): 1 = intersect skips tracing")
+    ap.add_argument("--debug-flags", type=int, default=0, help="A/B switches (16 / 32: result-neutral; 1-8 need a -DPT_ABLATE library)")
+    ap.add_argument("--arith", choices=["exact", "fma", "fast"], default="fast", help="arithmetic mode of the kernels (PT_ARITH_*)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket intersect launches with HIP events")
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and psnr (N=1 extras)")
     ap.add_argument("--save", type=str, default="", help="write the final image as PREFIX.png/.pfm")
@@ -130,7 +131,7 @@ def main() -> None:
         return capi.Renderer(scene, device=local_rank, **topt,
                              iters_per_batch=args.iters_per_batch, num_queues=args.queues,
                              blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels,
-                             legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags,
+                             legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags, arith=args.arith,
                              unfused_primary=args.unfused_primary, unfused_bounces=args.unfused_bounces)
 
     def barrier():

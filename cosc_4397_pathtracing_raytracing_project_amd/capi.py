@@ -14,8 +14,12 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libpt_amd.so")
+# PT_AMD_LIB lets experiment tooling (tools/ab*.sh, tools/pmc_*.sh) load an A/B build from elsewhere instead of
+# overwriting the in-tree product library.
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_PKG, "libpt_amd.so")
 PT_MAX_DEPTH = 64
+ARITH = {"exact": 0, "fma": 1, "fast": 2}  # PT_ARITH_* (include/pt_amd.h)
+ARITH_NAMES = {v: k for k, v in ARITH.items()}
 
 
 class PtGeom(C.Structure):
@@ -49,14 +53,15 @@ class PtOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("pixel_begin", C.c_int32), ("pixel_count", C.c_int32),
                 ("iters_per_batch", C.c_int32), ("num_queues", C.c_int32), ("blocks_per_cu", C.c_int32),
                 ("time_kernels", C.c_int32), ("legacy_traversal", C.c_int32), ("debug_flags", C.c_int32), ("unfused_primary", C.c_int32), ("unfused_bounces", C.c_int32), ("stripe_pixels", C.c_int32), ("stripe_stride", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("arith", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class PtStats(C.Structure):
     _fields_ = [("samples", C.c_int64), ("live_rays", C.c_int64 * PT_MAX_DEPTH), ("intersect_launches", C.c_int64),
                 ("intersect_ms", C.c_double), ("render_ms", C.c_double), ("num_cus", C.c_int32),
                 ("grid_blocks", C.c_int32), ("num_queues", C.c_int32), ("iters_per_batch", C.c_int32),
-                ("device_bytes", C.c_int64), ("primary_fused", C.c_int32), ("bounces_fused", C.c_int32)]
+                ("device_bytes", C.c_int64), ("primary_fused", C.c_int32), ("bounces_fused", C.c_int32),
+                ("arith", C.c_int32), ("pad_", C.c_int32)]
 
 
 class PtError(RuntimeError):
@@ -97,6 +102,29 @@ def lib() -> C.CDLL:
     L.pt_stage_generate.argtypes = [C.c_int, C.c_int, _fp, _fp]
     L.pt_stage_intersect.argtypes = [C.c_int, _fp, _fp, _fp, _fp, _ip, _fp]
     L.pt_stage_shade.argtypes = [C.c_int, C.c_int, _ip, _ip, _fp, _fp, _ip, _fp, _fp, _fp, _fp, _ip]
+    _u8p = C.POINTER(C.c_uint8)
+    L.pt_save_u8.argtypes = [C.c_float, _u8p]
+    L.pt_ctx_create.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), C.POINTER(C.c_void_p)]
+    L.pt_ctx_destroy.argtypes = [C.c_void_p]
+    L.pt_ctx_render.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.pt_ctx_sync.argtypes = [C.c_void_p]
+    L.pt_ctx_readback.argtypes = [C.c_void_p, _fp]
+    L.pt_ctx_readback_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.pt_ctx_save_u8.argtypes = [C.c_void_p, C.c_float, _u8p]
+    L.pt_ctx_get_stats.argtypes = [C.c_void_p, C.POINTER(PtStats)]
+    L.pt_ctx_reset_stats.argtypes = [C.c_void_p]
+    L.pt_ctx_pixel_count.argtypes = [C.c_void_p]
+    L.pt_group_create.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), _ip, C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_group_destroy.argtypes = [C.c_void_p]
+    L.pt_group_size.argtypes = [C.c_void_p]
+    L.pt_group_context.argtypes = [C.c_void_p, C.c_int]
+    L.pt_group_context.restype = C.c_void_p
+    L.pt_group_render.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.pt_group_sync.argtypes = [C.c_void_p]
+    L.pt_group_gather.argtypes = [C.c_void_p, _fp]
+    L.pt_group_gather_u8.argtypes = [C.c_void_p, C.c_float, _u8p]
+    L.pt_write_png_rgb8.argtypes = [C.c_char_p, _u8p, C.c_int, C.c_int]
+    L.pt_output_basename.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.pt_save_png.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
     L.pt_save_pfm.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
     _lib = L
@@ -174,27 +202,34 @@ def build_transform(trs: Sequence[float]):
     return m, i, it
 
 
-class Renderer:
-    """pathtraceInit / pathtrace / pathtraceFree over the C ABI (one global instance, like the reference)."""
+def make_options(device: int = 0, pixel_begin: int = 0, pixel_count: int = 0, iters_per_batch: int = 0,
+                 num_queues: int = 0, blocks_per_cu: int = 0, time_kernels: bool = False, legacy_traversal: bool = False,
+                 debug_flags: int = 0, unfused_primary: bool = False, unfused_bounces: bool = False,
+                 stripe_pixels: int = 0, stripe_stride: int = 0, arith="exact") -> PtOptions:
+    opt = PtOptions()
+    opt.device = device
+    opt.pixel_begin = pixel_begin
+    opt.pixel_count = pixel_count
+    opt.iters_per_batch = iters_per_batch
+    opt.num_queues = num_queues
+    opt.blocks_per_cu = blocks_per_cu
+    opt.time_kernels = 1 if time_kernels else 0
+    opt.legacy_traversal = 1 if legacy_traversal else 0
+    opt.debug_flags = int(debug_flags)
+    opt.unfused_primary = 1 if unfused_primary else 0
+    opt.unfused_bounces = 1 if unfused_bounces else 0
+    opt.stripe_pixels = int(stripe_pixels)
+    opt.stripe_stride = int(stripe_stride)
+    opt.arith = ARITH[arith] if isinstance(arith, str) else int(arith)
+    return opt
 
-    def __init__(self, scene: Scene, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0,
-                 iters_per_batch: int = 0, num_queues: int = 0, blocks_per_cu: int = 0, time_kernels: bool = False,
-                 legacy_traversal: bool = False, debug_flags: int = 0, unfused_primary: bool = False,
-                 unfused_bounces: bool = False, stripe_pixels: int = 0, stripe_stride: int = 0):
-        opt = PtOptions()
-        opt.device = device
-        opt.pixel_begin = pixel_begin
-        opt.pixel_count = pixel_count
-        opt.iters_per_batch = iters_per_batch
-        opt.num_queues = num_queues
-        opt.blocks_per_cu = blocks_per_cu
-        opt.time_kernels = 1 if time_kernels else 0
-        opt.legacy_traversal = 1 if legacy_traversal else 0
-        opt.debug_flags = int(debug_flags)
-        opt.unfused_primary = 1 if unfused_primary else 0
-        opt.unfused_bounces = 1 if unfused_bounces else 0
-        opt.stripe_pixels = int(stripe_pixels)
-        opt.stripe_stride = int(stripe_stride)
+
+class Renderer:
+    """pathtraceInit / pathtrace / pathtraceFree over the C ABI (the default instance, like the reference's
+    file-scope renderer state).  `arith`: "exact" (bit-identical to the oracle), "fma" or "fast" (PT_ARITH_*)."""
+
+    def __init__(self, scene: Scene, device: int = 0, pixel_begin: int = 0, pixel_count: int = 0, **kw):
+        opt = make_options(device=device, pixel_begin=pixel_begin, pixel_count=pixel_count, **kw)
         self.scene = scene
         w, h = scene.resolution
         self.n = pixel_count if pixel_count > 0 else w * h - pixel_begin
@@ -216,6 +251,13 @@ class Renderer:
 
     def readback_device(self, dev_ptr: int) -> None:
         _check(lib().pt_readback_device(C.c_void_p(dev_ptr)))
+
+    def save_u8(self, samples: float) -> np.ndarray:
+        """saveImage()'s bytes computed on the device: uint8 [rows, W, 3], x mirrored (whole-row tiles only)."""
+        w, _ = self.scene.resolution
+        out = np.empty((self.n // w, w, 3), np.uint8)
+        _check(lib().pt_save_u8(C.c_float(samples), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
 
     def preview(self, iterations: int) -> np.ndarray:
         out = np.empty((self.n, 4), np.uint8)
@@ -268,6 +310,55 @@ class Renderer:
 
 def pt_free() -> None:
     _check(lib().pt_free())
+
+
+class Group:
+    """pt_group_*: one process driving several GPUs, row-interleaved tiles, one RCCL gather at write-out."""
+
+    def __init__(self, scene: Scene, devices: Sequence[int], **kw):
+        self.scene = scene
+        self._h = C.c_void_p()
+        dev = np.asarray(list(devices), np.int32)
+        opt = make_options(**kw)
+        _check(lib().pt_group_create(C.byref(scene.desc), C.byref(opt), _i(dev), len(dev), C.byref(self._h)))
+
+    def render(self, iter_first: int, iter_count: int) -> None:
+        _check(lib().pt_group_render(self._h, int(iter_first), int(iter_count)))
+
+    def gather(self) -> np.ndarray:
+        w, h = self.scene.resolution
+        out = np.empty((w * h, 3), np.float32)
+        _check(lib().pt_group_gather(self._h, _f(out)))
+        return out
+
+    def gather_u8(self, samples: float) -> np.ndarray:
+        w, h = self.scene.resolution
+        out = np.empty((h, w, 3), np.uint8)
+        _check(lib().pt_group_gather_u8(self._h, C.c_float(samples), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def stats(self, i: int = 0) -> PtStats:
+        st = PtStats()
+        _check(lib().pt_ctx_get_stats(lib().pt_group_context(self._h, i), C.byref(st)))
+        return st
+
+    def free(self) -> None:
+        if self._h:
+            lib().pt_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def write_png_rgb8(path: str, rgb8: np.ndarray) -> None:
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    h, w = a.shape[0], a.shape[1]
+    if lib().pt_write_png_rgb8(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_uint8)), w, h) != 0:
+        raise PtError(f"cannot write {path}")
+
+
+def output_basename(name: str, samples: int) -> str:
+    buf = C.create_string_buffer(512)
+    lib().pt_output_basename(name.encode(), int(samples), buf, 512)
+    return buf.value.decode()
 
 
 def save_png(path: str, rgb_sum: np.ndarray, w: int, h: int, samples: float) -> None:

@@ -13,6 +13,7 @@ pt::Scene* hst_scene = nullptr;
 GuiDataContainer* guiData = nullptr;
 int q_first = 0, q_count = 0;  // queued, not yet submitted iterations [q_first, q_first+q_count)
 int last_iter = 0;
+int arith_mode = PT_ARITH_EXACT;
 
 void check(int rc, const char* what) {  // pathtrace.cu:141-150
   if (rc == 0) return;
@@ -26,11 +27,14 @@ void flush() {
 }  // namespace
 
 void InitDataContainer(GuiDataContainer* imGuiData) { guiData = imGuiData; }
+void pathtraceSetArith(int pt_arith) { arith_mode = pt_arith; }
 
 void pathtraceInit(pt::Scene* scene) {
   hst_scene = scene;
   PtSceneDesc d = scene->desc();
-  check(pt_init(&d, nullptr), "pathtraceInit");
+  PtOptions opt{};
+  opt.arith = arith_mode;
+  check(pt_init(&d, &opt), "pathtraceInit");
   q_count = 0;
   last_iter = 0;
 }

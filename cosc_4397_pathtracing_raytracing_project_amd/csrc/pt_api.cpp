@@ -19,13 +19,21 @@
 
 #include "../../include/pt_amd.h"
 #include "pt_device.h"
+#include "pt_internal.h"
 #include "pt_kernels.h"
 #include "pt_scene.h"
 
 namespace {
 
+#ifdef PT_ABLATE
+constexpr bool kAblateBuild = true;   // tools/pmc_ablate.sh A/B library: PtOptions.debug_flags bits 0-3 honoured
+#else
+constexpr bool kAblateBuild = false;  // release library: pt_init rejects them
+#endif
+
 std::string g_err;
-int fail(const char* fmt, ...) {
+}  // namespace
+int pt_fail(const char* fmt, ...) {  // pt_internal.h: sets pt_last_error(), returns -1
   char buf[1024];
   va_list ap;
   va_start(ap, fmt);
@@ -34,6 +42,8 @@ int fail(const char* fmt, ...) {
   g_err = buf;
   return -1;
 }
+namespace {
+#define fail pt_fail
 #define HIP_OK(expr)                                                                                   \
   do {                                                                                                 \
     hipError_t e_ = (expr);                                                                            \
@@ -44,10 +54,16 @@ struct EventPair {
   hipEvent_t a, b;
 };
 
-struct Ctx {
-  bool live = false;
+}  // namespace
+
+// One renderer instance = one device, one stream, one tile of the framebuffer.  The reference keeps this state in
+// file-scope statics (pathtrace.cu:446-456); here it is an object so that one process can drive several GPUs
+// (pt_group_*, pt_group.cpp) — the old single-instance entry points act on a default context.
+struct PtContext {
   int device = 0;
   hipStream_t stream = nullptr;
+  const ptk::KernelApi* k = nullptr;  // kernels of the selected arithmetic mode
+  int arith = 0;
   // scene
   std::vector<PtGeom> geoms;
   std::vector<PtMaterial> mats;
@@ -72,14 +88,16 @@ struct Ctx {
   float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
   float cull_margin = 0.f;
   unsigned long long top_xor = 0;  // SceneTables::top_xor
+  int lds_table_bytes = -1;        // SceneTables::lds_table_bytes
   bool legacy = false;
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
   int grid_primary = 0, grid_bounce = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
-  float* d_final = nullptr;
+  float4* d_final = nullptr;
   float* d_image = nullptr;
+  uint8_t* d_rgb8 = nullptr;  // lazily allocated output of pt_ctx_save_u8
   int32_t* d_cnt = nullptr;
   unsigned long long* d_stats = nullptr;
   // timing
@@ -89,10 +107,13 @@ struct Ctx {
   int64_t isect_launches = 0;
   int64_t samples = 0;
 };
-Ctx g;
+
+namespace {
+using Ctx = PtContext;
+Ctx* g_default = nullptr;  // the instance behind pt_init / pt_render / pt_free
 
 template <typename T>
-int dalloc(T** out, size_t count) {
+int dalloc(Ctx& g, T** out, size_t count) {
   void* p = nullptr;
   size_t bytes = std::max<size_t>(count * sizeof(T), 16);
   hipError_t e = hipMalloc(&p, bytes);
@@ -103,7 +124,7 @@ int dalloc(T** out, size_t count) {
   return 0;
 }
 
-int get_events(EventPair* ev) {
+int get_events(Ctx& g, EventPair* ev) {
   if (!g.free_events.empty()) {
     *ev = g.free_events.back();
     g.free_events.pop_back();
@@ -113,7 +134,7 @@ int get_events(EventPair* ev) {
   HIP_OK(hipEventCreate(&ev->b));
   return 0;
 }
-int resolve_events() {  // requires the stream to be idle
+int resolve_events(Ctx& g) {  // requires the stream to be idle
   for (auto& e : g.pending_isect) {
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, e.a, e.b));
@@ -240,7 +261,7 @@ void pack_rows(const float m16[16], float out12[12]) {
     for (int r = 0; r < 3; ++r) out12[c * 3 + r] = m16[c * 4 + r];
 }
 
-ptk::SceneTables tables() {
+ptk::SceneTables tables(const Ctx& g) {
   ptk::SceneTables t{};
   t.nodes = g.d_nodes;
   t.num_nodes = g.num_nodes;
@@ -249,96 +270,95 @@ ptk::SceneTables tables() {
   t.mats = g.d_mats;
   t.num_mats = (int)g.mats.size();
   t.top = g.d_top;
-  t.num_top = (g.debug_flags & 1) ? 0 : g.num_top;
+  t.num_top = (kAblateBuild && (g.debug_flags & 1)) ? 0 : g.num_top;
   std::memcpy(t.root_min, g.root_min, 12);
   std::memcpy(t.root_max, g.root_max, 12);
   t.cull_margin = (g.debug_flags & 16) ? INFINITY : g.cull_margin;
   t.top_xor = (g.debug_flags & 32) ? 0ull : g.top_xor;
+  t.lds_table_bytes = g.lds_table_bytes;
   return t;
 }
 
-int alloc_pathbuf(ptd::PathBuf* b, int64_t stride) {
+int alloc_pathbuf(Ctx& g, ptd::PathBuf* b, int64_t stride) {
   b->stride = stride;
-  if (dalloc(&b->o, 3 * stride)) return -1;
-  if (dalloc(&b->d, 3 * stride)) return -1;
-  if (dalloc(&b->c, 3 * stride)) return -1;
-  if (dalloc(&b->slot, stride)) return -1;
+  if (dalloc(g, &b->o, 3 * stride)) return -1;
+  if (dalloc(g, &b->d, 3 * stride)) return -1;
+  if (dalloc(g, &b->c, 3 * stride)) return -1;
+  if (dalloc(g, &b->slot, stride)) return -1;
   return 0;
 }
-int alloc_hitbuf(ptd::HitBuf* h, int64_t stride) {
+int alloc_hitbuf(Ctx& g, ptd::HitBuf* h, int64_t stride) {
   h->stride = stride;
-  if (dalloc(&h->t, stride)) return -1;
-  if (dalloc(&h->n, 3 * stride)) return -1;
-  if (dalloc(&h->mat, stride)) return -1;
-  if (dalloc(&h->p, 3 * stride)) return -1;
+  if (dalloc(g, &h->t, stride)) return -1;
+  if (dalloc(g, &h->n, 3 * stride)) return -1;
+  if (dalloc(g, &h->mat, stride)) return -1;
+  if (dalloc(g, &h->p, 3 * stride)) return -1;
   return 0;
 }
 
 // Queue descriptor for a launch of `grid` workgroups (W = waves of THAT launch; Q, cap shared).
-ptd::Queues queues_for(int grid) {
+ptd::Queues queues_for(const Ctx& g, int grid) {
   ptd::Queues q = g.qs;
   q.W = grid * ptk::kWavesPerBlock;
   return q;
 }
 
-int run_batch(int iter_first, int kb) {
+int run_batch(Ctx& g, int iter_first, int kb) {
   ptk::BatchInfo b{};
   b.iter_first = iter_first;
   b.K = kb;
   b.N = g.N;
   b.pixel_begin = g.pixel_begin;
   b.trace_depth = g.depth;
-  b.debug = g.debug_flags;
+  b.debug = kAblateBuild ? g.debug_flags : 0;
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;
   b.inv_stripe = g.stripe ? 1.0f / (float)g.stripe : 0.0f;
-  const ptk::SceneTables sc = tables();
+  const ptk::SceneTables sc = tables(g);
+  const ptk::KernelApi& k = *g.k;
   const size_t per_depth = (size_t)g.qs.Q * g.qs.cnt_stride;
   int d0 = 0;
   if (g.fuse_primary) {
     // depth 0 in one launch; its survivors are the depth-1 input (buf[1], cnt[1])
-    ptk::launch_primary(g.stream, g.grid_primary, sc, g.dcam, b, queues_for(g.grid_primary), g.d_cnt, g.d_cnt + per_depth,
-                        g.buf[1], g.d_final);
+    k.primary(g.stream, g.grid_primary, sc, g.dcam, b, queues_for(g, g.grid_primary), g.d_cnt, g.d_cnt + per_depth, g.buf[1],
+              g.d_final);
     d0 = 1;
   } else {
-    ptk::launch_generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g.grid_gen), g.buf[0], g.d_cnt);
+    k.generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g, g.grid_gen), g.buf[0], g.d_cnt);
   }
   for (int d = d0; d < g.depth; ++d) {
     const int32_t* cin = g.d_cnt + per_depth * d;
     int32_t* cout = g.d_cnt + per_depth * (d + 1);
     EventPair ev{};
     if (g.time_kernels) {  // brackets the dominant kernel of this depth
-      if (get_events(&ev)) return -1;
+      if (get_events(g, &ev)) return -1;
       HIP_OK(hipEventRecord(ev.a, g.stream));
     }
     if (g.fuse_bounces) {
-      ptk::launch_bounce(g.stream, g.grid_bounce, sc, b, d, queues_for(g.grid_bounce), cin, cout, g.buf[d & 1],
-                         g.buf[(d + 1) & 1], g.d_final);
+      k.bounce(g.stream, g.grid_bounce, sc, b, d, queues_for(g, g.grid_bounce), cin, cout, g.buf[d & 1], g.buf[(d + 1) & 1],
+               g.d_final);
     } else {
-      ptk::launch_intersect(g.stream, g.grid_isect, sc, queues_for(g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy);
+      k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy);
     }
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
       g.pending_isect.push_back(ev);
     }
     if (!g.fuse_bounces)
-      ptk::launch_shade(g.stream, g.grid_shade, sc, b, d, queues_for(g.grid_shade), cin, cout, g.buf[d & 1], g.hits,
-                        g.buf[(d + 1) & 1], g.d_final);
+      k.shade(g.stream, g.grid_shade, sc, b, d, queues_for(g, g.grid_shade), cin, cout, g.buf[d & 1], g.hits, g.buf[(d + 1) & 1],
+              g.d_final);
   }
-  ptk::launch_count_stats(g.stream, g.qs, g.d_cnt, g.depth, g.d_stats);
-  ptk::launch_gather(g.stream, b, g.d_final, g.d_image);
+  k.count_stats(g.stream, g.qs, g.d_cnt, g.depth, g.d_stats);
+  k.gather(g.stream, b, g.d_final, g.d_image);
   HIP_OK(hipGetLastError());
   g.samples += (int64_t)kb * g.N;
   if (g.pending_isect.size() > 16384) {
     HIP_OK(hipStreamSynchronize(g.stream));
-    if (resolve_events()) return -1;
+    if (resolve_events(g)) return -1;
   }
   return 0;
 }
 
-}  // namespace
-
-namespace {
 struct Scratch {  // frees on scope exit
   std::vector<void*> p;
   ~Scratch() {
@@ -352,7 +372,7 @@ struct Scratch {  // frees on scope exit
     return reinterpret_cast<T*>(q);
   }
 };
-ptd::Queues single_queue(int n) {
+ptd::Queues single_queue(const Ctx& g, int n) {
   ptd::Queues qs{};
   qs.Q = 1;
   qs.cap = ((n + 63) / 64) * 64;
@@ -360,58 +380,12 @@ ptd::Queues single_queue(int n) {
   qs.cnt_stride = 16;
   return qs;
 }
-}  // namespace
 
-extern "C" {
-
-const char* pt_last_error(void) { return g_err.c_str(); }
-
-// ---- scene -----------------------------------------------------------------
-struct PtScene {
-  pt::Scene scene;
-  explicit PtScene(const std::string& f) : scene(f) {}
-};
-
-int pt_scene_load(const char* path, int res_w, int res_h, PtScene** out) {
-  if (!path || !out) return fail("pt_scene_load: null argument");
-  try {
-    PtScene* s = new PtScene(path);
-    if (res_w > 0 && res_h > 0) s->scene.overrideResolution(res_w, res_h);
-    s->scene.applyInitialCameraState();
-    *out = s;
-    return 0;
-  } catch (const std::exception& e) {
-    return fail("pt_scene_load: %s", e.what());
-  }
-}
-void pt_scene_free(PtScene* s) { delete s; }
-int pt_scene_desc(const PtScene* s, PtSceneDesc* out) {
-  if (!s || !out) return fail("pt_scene_desc: null argument");
-  *out = s->scene.desc();
-  return 0;
-}
-int pt_scene_iterations(const PtScene* s) { return s ? (int)s->scene.state.iterations : 0; }
-const char* pt_scene_image_name(const PtScene* s) { return s ? s->scene.state.imageName.c_str() : ""; }
-
-int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap) {
-  std::vector<PtBVHNode> nodes;
-  pt::buildBVH(geoms, num_geoms, nodes);
-  if (out) std::memcpy(out, nodes.data(), sizeof(PtBVHNode) * std::min<size_t>(nodes.size(), (size_t)std::max(cap, 0)));
-  return (int)nodes.size();
-}
-
-int pt_build_transform(const float* trs, float* transform, float* inverse, float* invTranspose) {
-  if (!trs || !transform || !inverse || !invTranspose) return fail("pt_build_transform: null argument");
-  pt::buildTransform(trs, transform, inverse, invTranspose);
-  return 0;
-}
-
-// ---- renderer ----------------------------------------------------------------
-int pt_free(void) {
-  if (!g.live && g.allocs.empty()) return 0;  // pathtraceFree() before init / twice is legal (main.cpp:134)
-  (void)hipSetDevice(g.device);
-  if (g.stream) (void)hipStreamSynchronize(g.stream);
-  for (void* p : g.allocs) (void)hipFree(p);
+void destroy(Ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) (void)hipFree(p);
   auto kill = [](std::vector<EventPair>& v) {
     for (auto& e : v) {
       (void)hipEventDestroy(e.a);
@@ -419,28 +393,21 @@ int pt_free(void) {
     }
     v.clear();
   };
-  kill(g.free_events);
-  kill(g.pending_isect);
-  kill(g.pending_render);
-  if (g.stream) (void)hipStreamDestroy(g.stream);
-  g = Ctx();
-  return 0;
+  kill(c->free_events);
+  kill(c->pending_isect);
+  kill(c->pending_render);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
 }
 
-int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
-  if (!sc) return fail("pt_init: null scene");
-  if (sc->num_geoms <= 0 || !sc->geoms) return fail("pt_init: scene has no geometry");
-  if (sc->num_materials <= 0 || !sc->materials) return fail("pt_init: scene has no materials");
-  if (sc->trace_depth <= 0 || sc->trace_depth > PT_MAX_DEPTH) return fail("pt_init: trace_depth %d out of range", sc->trace_depth);
+// pathtraceInit (pathtrace.cu:462-516) for one context.  Any failure leaves nothing behind: the caller destroys `g`.
+int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   const int W = sc->camera.resolution[0], H = sc->camera.resolution[1];
-  if (W <= 0 || H <= 0 || (int64_t)W * H > (1ll << 30)) return fail("pt_init: bad resolution %dx%d", W, H);
-  for (int i = 0; i < sc->num_geoms; ++i)
-    if (sc->geoms[i].materialid < 0 || sc->geoms[i].materialid >= sc->num_materials)
-      return fail("pt_init: geom %d references material %d of %d", i, sc->geoms[i].materialid, sc->num_materials);
-  PtOptions opt{};
-  if (opt_in) opt = *opt_in;
-  pt_free();
-
+  g.arith = opt.arith;
+  g.k = ptk::api_for(opt.arith);
+  if (!g.k) return fail("pt_init: arith %d is not one of PT_ARITH_EXACT / PT_ARITH_FMA / PT_ARITH_FAST", opt.arith);
+  if (!kAblateBuild && (opt.debug_flags & 15))
+    return fail("pt_init: debug_flags bits 0-3 (ablations with wrong results) exist only in -DPT_ABLATE builds of the library");
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (ndev <= 0) return fail("pt_init: no HIP device (this library has no CPU fallback)");
@@ -451,7 +418,6 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   HIP_OK(hipGetDeviceProperties(&prop, g.device));
   g.num_cus = prop.multiProcessorCount;
   HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  g.live = true;
 
   g.geoms.assign(sc->geoms, sc->geoms + sc->num_geoms);
   g.mats.assign(sc->materials, sc->materials + sc->num_materials);
@@ -554,8 +520,8 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
     dm[i].emittance = g.mats[i].emittance;
   }
   if (dm.size() * sizeof(ptd::Mat) > 60 * 1024) return fail("pt_init: %zu materials exceed the LDS table", dm.size());
-  if (dalloc(&g.d_nodes, nodes.size()) || dalloc(&g.d_geoms, dg.size()) || dalloc(&g.d_mats, dm.size()) ||
-      dalloc(&g.d_top, top.size()))
+  if (dalloc(g, &g.d_nodes, nodes.size()) || dalloc(g, &g.d_geoms, dg.size()) || dalloc(g, &g.d_mats, dm.size()) ||
+      dalloc(g, &g.d_top, top.size()))
     return -1;
   HIP_OK(hipMemcpy(g.d_top, top.data(), top.size() * sizeof(ptd::TopEntry), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
@@ -563,24 +529,23 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
 
   {
-    const ptk::SceneTables t = tables();
     const char* kb = getenv("PT_LDS_TABLE_KB");  // test / experiment knob: force the LDS staging limit of the scene tables
-    if (kb) ptk::set_lds_table_limit(t, atoi(kb) * 1024);
-    else ptk::auto_lds_table_limit(t);
+    g.lds_table_bytes = g.k->lds_table_limit(tables(g), kb ? atoi(kb) * 1024 : -1);
+    const ptk::SceneTables t = tables(g);
     const int cap_bpc = opt.blocks_per_cu > 0 ? std::min(opt.blocks_per_cu, 8) : 8;
-    g.grid_gen = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kGenerate, t));
-    g.grid_isect = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
-    g.grid_shade = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kShade, t));
-    g.grid_primary = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kPrimary, t));
-    g.grid_bounce = g.num_cus * std::min(cap_bpc, ptk::resident_blocks_per_cu(ptk::kBounce, t));
+    g.grid_gen = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kGenerate, t));
+    g.grid_isect = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
+    g.grid_shade = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kShade, t));
+    g.grid_primary = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
+    g.grid_bounce = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounce, t));
   }
   // path state
-  if (alloc_pathbuf(&g.buf[0], g.stride) || alloc_pathbuf(&g.buf[1], g.stride)) return -1;
-  if (!g.fuse_bounces && alloc_hitbuf(&g.hits, g.stride)) return -1;  // hit records reach HBM only in the unfused form
-  if (dalloc(&g.d_final, 3 * (size_t)total) || dalloc(&g.d_image, 3 * (size_t)g.N)) return -1;
-  if (dalloc(&g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;
+  if (alloc_pathbuf(g, &g.buf[0], g.stride) || alloc_pathbuf(g, &g.buf[1], g.stride)) return -1;
+  if (!g.fuse_bounces && alloc_hitbuf(g, &g.hits, g.stride)) return -1;  // hit records reach HBM only in the unfused form
+  if (dalloc(g, &g.d_final, (size_t)total) || dalloc(g, &g.d_image, 3 * (size_t)g.N)) return -1;
+  if (dalloc(g, &g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;
   HIP_OK(hipMemset(g.d_cnt, 0, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride * sizeof(int32_t)));  // k_count_stats re-zeroes it after every batch
-  if (dalloc(&g.d_stats, PT_MAX_DEPTH)) return -1;
+  if (dalloc(g, &g.d_stats, PT_MAX_DEPTH)) return -1;
   HIP_OK(hipMemset(g.d_image, 0, 3 * (size_t)g.N * sizeof(float)));
   HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));
   g.time_kernels = opt.time_kernels != 0;
@@ -588,72 +553,183 @@ int pt_init(const PtSceneDesc* sc, const PtOptions* opt_in) {
   return 0;
 }
 
-int pt_render(int iter_first, int iter_count) {
-  if (!g.live) return fail("pt_render: pt_init has not been called");
+int need(const PtContext* c, const char* who) {
+  if (!c) return fail("%s: pt_init has not been called", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+int pt_library_has_ablations(void) { return kAblateBuild ? 1 : 0; }
+
+// ---- scene -----------------------------------------------------------------
+struct PtScene {
+  pt::Scene scene;
+  explicit PtScene(const std::string& f) : scene(f) {}
+};
+
+int pt_scene_load(const char* path, int res_w, int res_h, PtScene** out) {
+  if (!path || !out) return fail("pt_scene_load: null argument");
+  try {
+    PtScene* s = new PtScene(path);
+    if (res_w > 0 && res_h > 0) s->scene.overrideResolution(res_w, res_h);
+    s->scene.applyInitialCameraState();
+    *out = s;
+    return 0;
+  } catch (const std::exception& e) {
+    return fail("pt_scene_load: %s", e.what());
+  }
+}
+void pt_scene_free(PtScene* s) { delete s; }
+int pt_scene_desc(const PtScene* s, PtSceneDesc* out) {
+  if (!s || !out) return fail("pt_scene_desc: null argument");
+  *out = s->scene.desc();
+  return 0;
+}
+int pt_scene_iterations(const PtScene* s) { return s ? (int)s->scene.state.iterations : 0; }
+const char* pt_scene_image_name(const PtScene* s) { return s ? s->scene.state.imageName.c_str() : ""; }
+
+int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap) {
+  std::vector<PtBVHNode> nodes;
+  pt::buildBVH(geoms, num_geoms, nodes);
+  if (out) std::memcpy(out, nodes.data(), sizeof(PtBVHNode) * std::min<size_t>(nodes.size(), (size_t)std::max(cap, 0)));
+  return (int)nodes.size();
+}
+
+int pt_build_transform(const float* trs, float* transform, float* inverse, float* invTranspose) {
+  if (!trs || !transform || !inverse || !invTranspose) return fail("pt_build_transform: null argument");
+  pt::buildTransform(trs, transform, inverse, invTranspose);
+  return 0;
+}
+
+// ---- renderer contexts ---------------------------------------------------------
+int pt_ctx_create(const PtSceneDesc* sc, const PtOptions* opt_in, PtContext** out) {
+  if (!out) return fail("pt_ctx_create: null output");
+  *out = nullptr;
+  if (!sc) return fail("pt_init: null scene");
+  if (sc->num_geoms <= 0 || !sc->geoms) return fail("pt_init: scene has no geometry");
+  if (sc->num_materials <= 0 || !sc->materials) return fail("pt_init: scene has no materials");
+  if (sc->trace_depth <= 0 || sc->trace_depth > PT_MAX_DEPTH) return fail("pt_init: trace_depth %d out of range", sc->trace_depth);
+  const int W = sc->camera.resolution[0], H = sc->camera.resolution[1];
+  if (W <= 0 || H <= 0 || (int64_t)W * H > (1ll << 30)) return fail("pt_init: bad resolution %dx%d", W, H);
+  for (int i = 0; i < sc->num_geoms; ++i)
+    if (sc->geoms[i].materialid < 0 || sc->geoms[i].materialid >= sc->num_materials)
+      return fail("pt_init: geom %d references material %d of %d", i, sc->geoms[i].materialid, sc->num_materials);
+  PtOptions opt{};
+  if (opt_in) opt = *opt_in;
+  PtContext* c = new PtContext();
+  if (setup(*c, sc, opt)) {  // nothing half-initialised survives a failure
+    destroy(c);
+    return -1;
+  }
+  *out = c;
+  return 0;
+}
+
+int pt_ctx_destroy(PtContext* c) {
+  if (c == g_default) g_default = nullptr;
+  destroy(c);
+  return 0;
+}
+
+int pt_ctx_render(PtContext* c, int iter_first, int iter_count) {
+  if (need(c, "pt_render")) return -1;
   if (iter_count <= 0) return 0;
+  Ctx& g = *c;
   HIP_OK(hipSetDevice(g.device));
   EventPair ev{};
-  if (get_events(&ev)) return -1;
+  if (get_events(g, &ev)) return -1;
   HIP_OK(hipEventRecord(ev.a, g.stream));
   const int end = iter_first + iter_count;
   for (int it = iter_first; it < end; it += g.K)
-    if (run_batch(it, std::min(g.K, end - it))) return -1;
+    if (run_batch(g, it, std::min(g.K, end - it))) return -1;
   HIP_OK(hipEventRecord(ev.b, g.stream));
   g.pending_render.push_back(ev);
   return 0;
 }
 
-int pt_sync(void) {
-  if (!g.live) return fail("pt_sync: pt_init has not been called");
-  HIP_OK(hipSetDevice(g.device));
-  HIP_OK(hipStreamSynchronize(g.stream));
-  return resolve_events();
+int pt_ctx_sync(PtContext* c) {
+  if (need(c, "pt_sync")) return -1;
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return resolve_events(*c);
 }
 
-int pt_readback(float* out) {
-  if (!g.live) return fail("pt_readback: pt_init has not been called");
+int pt_ctx_readback(PtContext* c, float* out) {
+  if (need(c, "pt_readback")) return -1;
   if (!out) return fail("pt_readback: null buffer");
-  HIP_OK(hipSetDevice(g.device));
-  HIP_OK(hipMemcpyAsync(out, g.d_image, 3 * (size_t)g.N * sizeof(float), hipMemcpyDeviceToHost, g.stream));
-  return pt_sync();
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipMemcpyAsync(out, c->d_image, 3 * (size_t)c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  return pt_ctx_sync(c);
 }
 
-int pt_readback_device(void* out) {
-  if (!g.live) return fail("pt_readback_device: pt_init has not been called");
+int pt_ctx_readback_device(PtContext* c, void* out) {
+  if (need(c, "pt_readback_device")) return -1;
   if (!out) return fail("pt_readback_device: null buffer");
-  HIP_OK(hipSetDevice(g.device));
-  HIP_OK(hipMemcpyAsync(out, g.d_image, 3 * (size_t)g.N * sizeof(float), hipMemcpyDeviceToDevice, g.stream));
-  return pt_sync();
+  HIP_OK(hipSetDevice(c->device));
+  HIP_OK(hipMemcpyAsync(out, c->d_image, 3 * (size_t)c->N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return pt_ctx_sync(c);
 }
 
-int pt_preview_rgba8(int iterations, uint8_t* rgba_host) {
-  if (!g.live) return fail("pt_preview_rgba8: pt_init has not been called");
-  if (!rgba_host || iterations <= 0) return fail("pt_preview_rgba8: bad argument");
+const float* pt_ctx_device_image(PtContext* c) { return c ? c->d_image : nullptr; }
+void* pt_ctx_stream(PtContext* c) { return c ? (void*)c->stream : nullptr; }
+int pt_ctx_pixel_count(const PtContext* c) { return c ? c->N : 0; }
+int pt_ctx_device(const PtContext* c) { return c ? c->device : -1; }
+
+// saveImage's conversion on the device; leaves the bytes in a device buffer owned by the context.
+int pt_ctx_save_u8_device(PtContext* c, float samples, const uint8_t** rgb8_dev) {
+  if (need(c, "pt_save_u8")) return -1;
+  Ctx& g = *c;
+  const int W = g.cam.resolution[0];
+  if (!(samples > 0.0f)) return fail("pt_save_u8: samples must be positive");
+  if (g.pixel_begin % W || g.N % W || (g.stripe && g.stripe != W))
+    return fail("pt_save_u8: the tile must consist of whole image rows (begin %d, count %d, stripe %d, width %d)", g.pixel_begin, g.N, g.stripe, W);
   HIP_OK(hipSetDevice(g.device));
+  if (!g.d_rgb8 && dalloc(g, &g.d_rgb8, 3 * (size_t)g.N)) return -1;
+  g.k->save_u8(g.stream, g.N, W, samples, g.d_image, g.d_rgb8);
+  HIP_OK(hipGetLastError());
+  if (rgb8_dev) *rgb8_dev = g.d_rgb8;
+  return 0;
+}
+int pt_ctx_save_u8(PtContext* c, float samples, uint8_t* rgb8_host) {
+  if (!rgb8_host) return fail("pt_save_u8: null buffer");
+  const uint8_t* d = nullptr;
+  if (pt_ctx_save_u8_device(c, samples, &d)) return -1;
+  HIP_OK(hipMemcpyAsync(rgb8_host, d, 3 * (size_t)c->N, hipMemcpyDeviceToHost, c->stream));
+  return pt_ctx_sync(c);
+}
+
+int pt_ctx_preview_rgba8_device(PtContext* c, int iterations, void* rgba_dev) {
+  if (need(c, "pt_preview_rgba8_device")) return -1;
+  if (!rgba_dev || iterations <= 0) return fail("pt_preview_rgba8_device: bad argument");
+  HIP_OK(hipSetDevice(c->device));
+  c->k->preview(c->stream, c->N, iterations, c->d_image, reinterpret_cast<uchar4*>(rgba_dev));
+  HIP_OK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pt_ctx_preview_rgba8(PtContext* c, int iterations, uint8_t* rgba_host) {
+  if (need(c, "pt_preview_rgba8")) return -1;
+  if (!rgba_host || iterations <= 0) return fail("pt_preview_rgba8: bad argument");
+  HIP_OK(hipSetDevice(c->device));
   uchar4* d = nullptr;
-  HIP_OK(hipMalloc((void**)&d, (size_t)g.N * 4));
-  ptk::launch_preview(g.stream, g.N, iterations, g.d_image, d);
-  hipError_t e = hipMemcpyAsync(rgba_host, d, (size_t)g.N * 4, hipMemcpyDeviceToHost, g.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+  HIP_OK(hipMalloc((void**)&d, (size_t)c->N * 4));
+  c->k->preview(c->stream, c->N, iterations, c->d_image, d);
+  hipError_t e = hipMemcpyAsync(rgba_host, d, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d);
   if (e != hipSuccess) return fail("pt_preview_rgba8: %s", hipGetErrorString(e));
   return 0;
 }
 
-
-int pt_preview_rgba8_device(int iterations, void* rgba_dev) {
-  if (!g.live) return fail("pt_preview_rgba8_device: pt_init has not been called");
-  if (!rgba_dev || iterations <= 0) return fail("pt_preview_rgba8_device: bad argument");
-  HIP_OK(hipSetDevice(g.device));
-  ptk::launch_preview(g.stream, g.N, iterations, g.d_image, reinterpret_cast<uchar4*>(rgba_dev));
-  HIP_OK(hipStreamSynchronize(g.stream));
-  return 0;
-}
-
-int pt_get_stats(PtStats* out) {
-  if (!g.live) return fail("pt_get_stats: pt_init has not been called");
+int pt_ctx_get_stats(PtContext* c, PtStats* out) {
+  if (need(c, "pt_get_stats")) return -1;
   if (!out) return fail("pt_get_stats: null");
-  if (pt_sync()) return -1;
+  if (pt_ctx_sync(c)) return -1;
+  Ctx& g = *c;
   std::memset(out, 0, sizeof(*out));
   unsigned long long st[PT_MAX_DEPTH];
   HIP_OK(hipMemcpy(st, g.d_stats, sizeof(st), hipMemcpyDeviceToHost));
@@ -663,33 +739,59 @@ int pt_get_stats(PtStats* out) {
   out->intersect_ms = g.isect_ms;
   out->render_ms = g.render_ms;
   out->num_cus = g.num_cus;
-  out->grid_blocks = g.grid_isect;
+  out->grid_blocks = g.fuse_bounces ? g.grid_bounce : g.grid_isect;
   out->num_queues = g.qs.Q;
   out->iters_per_batch = g.K;
   out->device_bytes = g.device_bytes;
   out->primary_fused = g.fuse_primary ? 1 : 0;
   out->bounces_fused = g.fuse_bounces ? 1 : 0;
+  out->arith = g.arith;
   return 0;
 }
 
-int pt_reset_stats(void) {
-  if (!g.live) return fail("pt_reset_stats: pt_init has not been called");
-  if (pt_sync()) return -1;
-  HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));
+int pt_ctx_reset_stats(PtContext* c) {
+  if (need(c, "pt_reset_stats")) return -1;
+  if (pt_ctx_sync(c)) return -1;
+  Ctx& g = *c;
+  // on the render stream (created non-blocking: the null stream would not be ordered against it)
+  HIP_OK(hipMemsetAsync(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long), g.stream));
+  HIP_OK(hipStreamSynchronize(g.stream));
   g.samples = 0;
   g.isect_ms = g.render_ms = 0;
   g.isect_launches = 0;
   return 0;
 }
 
-// ---- stage entry points (tests) ------------------------------------------------
+// ---- the reference's single-instance API (pathtrace.h) on a default context -------------
+int pt_free(void) {  // pathtraceFree() before init / twice is legal (main.cpp:134)
+  PtContext* c = g_default;
+  g_default = nullptr;
+  destroy(c);
+  return 0;
+}
+int pt_init(const PtSceneDesc* sc, const PtOptions* opt) {
+  pt_free();
+  return pt_ctx_create(sc, opt, &g_default);
+}
+int pt_render(int iter_first, int iter_count) { return pt_ctx_render(g_default, iter_first, iter_count); }
+int pt_sync(void) { return pt_ctx_sync(g_default); }
+int pt_readback(float* out) { return pt_ctx_readback(g_default, out); }
+int pt_readback_device(void* out) { return pt_ctx_readback_device(g_default, out); }
+int pt_save_u8(float samples, uint8_t* rgb8_host) { return pt_ctx_save_u8(g_default, samples, rgb8_host); }
+int pt_preview_rgba8(int iterations, uint8_t* rgba_host) { return pt_ctx_preview_rgba8(g_default, iterations, rgba_host); }
+int pt_preview_rgba8_device(int iterations, void* rgba_dev) { return pt_ctx_preview_rgba8_device(g_default, iterations, rgba_dev); }
+int pt_get_stats(PtStats* out) { return pt_ctx_get_stats(g_default, out); }
+int pt_reset_stats(void) { return pt_ctx_reset_stats(g_default); }
+
+// ---- stage entry points (tests; default context) ------------------------------------------------
 
 int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
-  if (!g.live) return fail("pt_stage_generate: pt_init has not been called");
+  if (need(g_default, "pt_stage_generate")) return -1;
+  Ctx& g = *g_default;
   if (n <= 0) return 0;
   HIP_OK(hipSetDevice(g.device));
   Scratch sc;
-  ptd::Queues qs = single_queue(n);
+  ptd::Queues qs = single_queue(g, n);
   ptd::PathBuf pb{};
   pb.stride = qs.cap;
   pb.o = sc.get<float>(3 * (size_t)qs.cap);
@@ -700,7 +802,7 @@ int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
   if (!pb.o || !pb.d || !pb.c || !pb.slot || !cnt) return fail("pt_stage_generate: out of device memory");
   ptk::BatchInfo b{};
   b.iter_first = 1, b.K = 1, b.N = n, b.pixel_begin = pix_begin, b.trace_depth = g.depth;
-  ptk::launch_generate(g.stream, g.grid, g.dcam, b, qs, pb, cnt);
+  g.k->generate(g.stream, g.grid, g.dcam, b, qs, pb, cnt);
   HIP_OK(hipStreamSynchronize(g.stream));
   for (int c = 0; c < 3; ++c) {
     HIP_OK(hipMemcpy(origin + (size_t)c * n, pb.o + (size_t)c * qs.cap, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -711,11 +813,12 @@ int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
 
 int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, float* normal, int32_t* material,
                        float* point) {
-  if (!g.live) return fail("pt_stage_intersect: pt_init has not been called");
+  if (need(g_default, "pt_stage_intersect")) return -1;
+  Ctx& g = *g_default;
   if (n <= 0) return 0;
   HIP_OK(hipSetDevice(g.device));
   Scratch sc;
-  ptd::Queues qs = single_queue(n);
+  ptd::Queues qs = single_queue(g, n);
   const size_t cap = qs.cap;
   ptd::PathBuf pb{};
   pb.stride = cap;
@@ -734,7 +837,7 @@ int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, f
     HIP_OK(hipMemcpy(pb.d + c * cap, dir + (size_t)c * n, (size_t)n * 4, hipMemcpyHostToDevice));
   }
   HIP_OK(hipMemcpy(cnt, &n, 4, hipMemcpyHostToDevice));
-  ptk::launch_intersect(g.stream, g.grid, tables(), qs, cnt, pb, hb, g.legacy);
+  g.k->intersect(g.stream, g.grid, tables(g), qs, cnt, pb, hb, g.legacy);
   HIP_OK(hipStreamSynchronize(g.stream));
   HIP_OK(hipMemcpy(t, hb.t, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(material, hb.mat, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -748,7 +851,8 @@ int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, f
 int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, const float* t, const float* normal,
                    const int32_t* material, const float* point, float* origin, float* dir, float* color,
                    int32_t* alive) {
-  if (!g.live) return fail("pt_stage_shade: pt_init has not been called");
+  if (need(g_default, "pt_stage_shade")) return -1;
+  Ctx& g = *g_default;
   if (n <= 0) return 0;
   if (depth < 0 || depth >= g.depth) return fail("pt_stage_shade: depth %d outside [0,%d)", depth, g.depth);
   for (int i = 0; i < n; ++i)
@@ -783,7 +887,7 @@ int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, 
   HIP_OK(hipMemcpy(hb.p, point, b3, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(d_iter, iter, b1, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(d_pix, pixel, b1, hipMemcpyHostToDevice));
-  ptk::launch_shade_stage(g.stream, tables(), g.depth, depth, n, d_iter, d_pix, hb, pb, d_alive);
+  g.k->shade_stage(g.stream, tables(g), g.depth, depth, n, d_iter, d_pix, hb, pb, d_alive);
   HIP_OK(hipStreamSynchronize(g.stream));
   HIP_OK(hipMemcpy(origin, pb.o, b3, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(dir, pb.d, b3, hipMemcpyDeviceToHost));

@@ -5,6 +5,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <algorithm>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -68,19 +71,13 @@ uint8_t to_u8(float v) {
 
 extern "C" {
 
-int pt_save_png(const char* path, const float* rgb_sum, int w, int h, float samples) {
-  if (!path || !rgb_sum || w <= 0 || h <= 0) return -1;
+int pt_write_png_rgb8(const char* path, const uint8_t* rgb8, int w, int h) {
+  if (!path || !rgb8 || w <= 0 || h <= 0) return -1;
   std::vector<uint8_t> raw;
   raw.reserve((size_t)h * (3 * (size_t)w + 1));
   for (int y = 0; y < h; ++y) {
     raw.push_back(0);  // filter: none
-    for (int x = 0; x < w; ++x) {
-      // saveImage(): img.setPixel(width - 1 - x, y, pix / samples) — output column x shows source column w-1-x
-      const float* s = rgb_sum + 3 * ((size_t)(w - 1 - x) + (size_t)y * w);
-      raw.push_back(to_u8(s[0] / samples));
-      raw.push_back(to_u8(s[1] / samples));
-      raw.push_back(to_u8(s[2] / samples));
-    }
+    raw.insert(raw.end(), rgb8 + (size_t)y * 3 * w, rgb8 + (size_t)(y + 1) * 3 * w);
   }
   std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
   std::vector<uint8_t> ihdr;
@@ -94,6 +91,39 @@ int pt_save_png(const char* path, const float* rgb_sum, int w, int h, float samp
   const size_t n = fwrite(out.data(), 1, out.size(), f);
   fclose(f);
   return n == out.size() ? 0 : -1;
+}
+
+int pt_save_png(const char* path, const float* rgb_sum, int w, int h, float samples) {
+  if (!path || !rgb_sum || w <= 0 || h <= 0) return -1;
+  std::vector<uint8_t> bytes((size_t)w * h * 3);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      // saveImage(): img.setPixel(width - 1 - x, y, pix / samples) — output column x shows source column w-1-x
+      const float* s = rgb_sum + 3 * ((size_t)(w - 1 - x) + (size_t)y * w);
+      uint8_t* d = bytes.data() + 3 * ((size_t)x + (size_t)y * w);
+      d[0] = to_u8(s[0] / samples), d[1] = to_u8(s[1] / samples), d[2] = to_u8(s[2] / samples);
+    }
+  return pt_write_png_rgb8(path, bytes.data(), w, h);
+}
+
+int pt_output_basename(const char* name, int samples, char* out, int cap) {
+  static std::string start_time;  // main.cpp:35: taken once, at program start
+  if (start_time.empty()) {
+    time_t now;
+    time(&now);
+    char buf[sizeof "0000-00-00_00-00-00z"];
+    strftime(buf, sizeof buf, "%Y-%m-%d_%H-%M-%Sz", gmtime(&now));
+    start_time = buf;
+  }
+  std::ostringstream ss;
+  ss << (name ? name : "") << "." << start_time << "." << (float)samples << "samp";
+  const std::string s = ss.str();
+  if (out && cap > 0) {
+    const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+    std::memcpy(out, s.data(), n);
+    out[n] = 0;
+  }
+  return (int)s.size();
 }
 
 // Little-endian PFM, rows bottom-to-top per the format; raw orientation (no x mirror),

@@ -34,6 +34,9 @@ struct SceneTables {
   // Near-first subtree order: byte k = XOR mask for rays whose direction sign bits are k = sx | sy << 1 | sz << 2
   // (pt_kernels.hip permute_xor); 0 when the top list is not a complete level of the tree.
   unsigned long long top_xor;
+  // Host-side decision (KernelApi::auto_lds_table_limit): nodes + geoms up to this many bytes are staged in LDS by
+  // the traversal kernels; -1: never.  Part of the tables so that several renderer contexts can differ.
+  int32_t lds_table_bytes;
 };
 
 struct BatchInfo {
@@ -46,49 +49,66 @@ struct BatchInfo {
   int32_t stripe, gap;
   float inv_stripe;
   int32_t trace_depth;
-  int32_t debug;  // profiling ablations (wrong results): 4 = skip primitive tests, 8 = skip shade_bounce
+  int32_t debug;  // profiling ablations (wrong results; honoured only by -DPT_ABLATE builds): 4 = skip primitive tests,
+                  // 8 = skip shade_bounce
 };
-
-// generateRayFromCamera for all K*N samples of a batch, straight into the queues.
-// Also writes the queue fill counts cnt0[q*cnt_stride].
-void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
-                     ptd::PathBuf out, int32_t* cnt0);
-// Depth 0 fused (generate + intersect + shade + compaction): survivors go to `out` / cnt_out (the depth-1
-// queues), retired samples to final_rgb; cnt0 receives the per-queue sample counts (statistics only).
-void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
-                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float* final_rgb);
-// Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.
-void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
-                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float* final_rgb);
-// computeIntersections over the live paths of every queue.
-void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
-                      ptd::PathBuf paths, ptd::HitBuf hits, bool legacy = false);
-// shadeAndExtendRays + compaction + retirement.
-void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
-                  const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                  float* final_rgb /* [3][K*N] planes */);
-// finalGather: image[p] += final[0][p] + final[1][p] + ... in iteration order.
-void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, float* image_rgb /* [N][3] */);
-// live-ray bookkeeping: stats[d] += sum_q cnt[d][q]
-void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count,
-                        unsigned long long* stats);
-// sendImageToPBO (pathtrace.cu:250-268)
-void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba);
 
 // Resident workgroups per CU for each persistent kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor),
 // so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
 // a workgroup that has to wait for a free slot would run its whole share after everybody else.
 enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kBounce = 5 };
-// Scene tables (nodes + geoms) up to this many bytes are staged in LDS by the traversal kernels (only scenes whose
-// leaves all fit the top list; test / experiment knob) ...
-void set_lds_table_limit(const SceneTables& sc, int bytes);
-// ... or, by default, exactly when staging them costs the bounce kernel no resident block per CU.
-void auto_lds_table_limit(const SceneTables& sc);
-int resident_blocks_per_cu(KernelId id, const SceneTables& sc);
 
-// Stage helper for tests: one shading step on n explicit paths (single queue, no compaction):
-// writes alive flags and in-place o/d/color.
-void launch_shade_stage(hipStream_t s, const SceneTables& sc, int trace_depth, int depth, int n, const int32_t* iter,
-                        const int32_t* pixel, ptd::HitBuf hits, ptd::PathBuf paths, int32_t* alive);
+// pt_kernels.hip is compiled once per arithmetic mode (PtOptions.arith, include/pt_amd.h):
+//   0 exact  -ffp-contract=off, every operation in the reference's order: bit-identical to oracle/pt_oracle.cpp
+//            (PORTABLE mode) — the parity anchor;
+//   1 fma    the same source with FMA contraction allowed (what nvcc does to the reference by default), IEEE
+//            divide / sqrt kept;
+//   2 fast   fma + hardware reciprocal / rsqrt / sqrt / sin / cos (all <= 1 ulp or ~1e-6 absolute), nested-FMA
+//            matrix products, float-only direction sampling.
+// Modes 1 and 2 are checked against the oracle's reference semantics (LIBM mode) with the tolerance of
+// SURVEY.md §8(c).  Each build exports its launch functions through this table.
+struct KernelApi {
+  const char* name;
+  // generateRayFromCamera for all K*N samples of a batch, straight into the queues.
+  // Also writes the queue fill counts cnt0[q*cnt_stride].
+  void (*generate)(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
+                   ptd::PathBuf out, int32_t* cnt0);
+  // Depth 0 fused (generate + intersect + shade + compaction): survivors go to `out` / cnt_out (the depth-1
+  // queues), retired samples to final_rgba; cnt0 receives the per-queue sample counts (statistics only).
+  void (*primary)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
+                  const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float4* final_rgba);
+  // Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.
+  void (*bounce)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
+                 const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba);
+  // computeIntersections over the live paths of every queue.
+  void (*intersect)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
+                    ptd::PathBuf paths, ptd::HitBuf hits, bool legacy);
+  // shadeAndExtendRays + compaction + retirement.
+  void (*shade)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
+                const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
+                float4* final_rgba /* [K*N] one record per sample */);
+  // finalGather: image[p] += final[0][p] + final[1][p] + ... in iteration order.
+  void (*gather)(hipStream_t s, const BatchInfo& b, const float4* final_rgba, float* image_rgb /* [N][3] */);
+  // live-ray bookkeeping: stats[d] += sum_q cnt[d][q]
+  void (*count_stats)(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count, unsigned long long* stats);
+  // sendImageToPBO (pathtrace.cu:250-268)
+  void (*preview)(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba);
+  // saveImage + image::savePNG arithmetic on the device (main.cpp:86-107, image.cpp:22-39) for a tile of n pixels
+  // made of whole rows: clamp(sum / samples, 0, 1) * 255 truncated, 3 bytes per pixel, x mirrored inside each row.
+  void (*save_u8)(hipStream_t s, int n, int width, float samples, const float* image_rgb, uint8_t* rgb8);
+  // Stage helper for tests: one shading step on n explicit paths (single queue, no compaction):
+  // writes alive flags and in-place o/d/color.
+  void (*shade_stage)(hipStream_t s, const SceneTables& sc, int trace_depth, int depth, int n, const int32_t* iter,
+                      const int32_t* pixel, ptd::HitBuf hits, ptd::PathBuf paths, int32_t* alive);
+  // Scene tables (nodes + geoms) up to the returned number of bytes are staged in LDS by the traversal kernels:
+  // `forced_bytes` >= 0 is a test / experiment knob (only honoured for scenes whose leaves all fit the top list),
+  // otherwise exactly when staging them costs the bounce kernel no resident block per CU.
+  int (*lds_table_limit)(const SceneTables& sc, int forced_bytes);
+  int (*resident_blocks_per_cu)(KernelId id, const SceneTables& sc);
+};
+const KernelApi* api_exact();
+const KernelApi* api_fma();
+const KernelApi* api_fast();
+inline const KernelApi* api_for(int arith) { return arith == 0 ? api_exact() : arith == 1 ? api_fma() : arith == 2 ? api_fast() : nullptr; }
 
 }  // namespace ptk

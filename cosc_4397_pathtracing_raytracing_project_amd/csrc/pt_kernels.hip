@@ -11,6 +11,7 @@
 //                rule of SURVEY.md §8a and the compaction the reference never had
 //   k_gather     finalGather             src/pathtrace.cu:439-444
 //   k_preview    sendImageToPBO          src/pathtrace.cu:250-268
+//   k_save_u8    saveImage + savePNG     src/main.cpp:86-107, src/image.cpp:22-39
 // and the two kernels the default pipeline actually runs, which fuse the above per depth so that
 // neither the primary ray nor the hit record ever goes through HBM:
 //   k_primary    depth 0:  generate + intersect + shade + compaction
@@ -18,21 +19,50 @@
 // (k_generate / k_intersect / k_shade remain as the unfused form for stage-parity tests and A/B runs,
 // k_intersect_legacy as the per-lane tree walk the wave-cooperative search replaced.)
 //
-// Arithmetic contract: compiled with -ffp-contract=off; every float operation is
-// written in the order GLM 0.9.6 / the reference evaluate it, divisions and square
-// roots are IEEE (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), and
-// sin/cos/acos come from pt_portable_math.h, so results are bit-identical to
-// oracle/pt_oracle.cpp in PORTABLE mode.  No MFMA: there is no dense contraction here.
+// Arithmetic contract.  This file is compiled once per arithmetic mode (PT_ARITH, see pt_kernels.h KernelApi):
+//   0 exact: -ffp-contract=off; every float operation is written in the order GLM 0.9.6 / the reference
+//            evaluate it, divisions and square roots are IEEE (hipcc default
+//            -fhip-fp32-correctly-rounded-divide-sqrt), and sin/cos/acos come from pt_portable_math.h, so
+//            results are bit-identical to oracle/pt_oracle.cpp in PORTABLE mode;
+//   1 fma:   the same source with contraction allowed;
+//   2 fast:  the `kFast` branches below — hardware rcp / rsq / sqrt / sin / cos, nested-FMA matrix products,
+//            float-only direction sampling.  Same algorithm, same RNG draws, same decisions; only rounding differs.
+// No MFMA: there is no dense contraction here.
 #include "pt_kernels.h"
 
 #include <float.h>
 
 #include "pt_portable_math.h"
 
+#ifndef PT_ARITH
+#define PT_ARITH 0
+#endif
+#if PT_ARITH == 0
+#define PT_NS arith_exact
+#define PT_API_FN api_exact
+#elif PT_ARITH == 1
+#define PT_NS arith_fma
+#define PT_API_FN api_fma
+#elif PT_ARITH == 2
+#define PT_NS arith_fast
+#define PT_API_FN api_fast
+#else
+#error "PT_ARITH must be 0, 1 or 2"
+#endif
+
 namespace ptk {
+namespace PT_NS {
 namespace {
 
 #define PT_DEV __device__ __forceinline__
+
+constexpr bool kFast = PT_ARITH == 2;
+// Ablation switches of tools/pmc_ablate.sh (BatchInfo::debug, wrong results) exist only in -DPT_ABLATE builds.
+#ifdef PT_ABLATE
+constexpr bool kAblate = true;
+#else
+constexpr bool kAblate = false;
+#endif
 
 // Tuning switch of the large-scene (global-table) path, overridable with -D for A/B builds.
 #ifndef PT_STEAL_MIN
@@ -49,14 +79,36 @@ PT_DEV f3 sub(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 PT_DEV f3 mul(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_DEV f3 scl(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 PT_DEV f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
-PT_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Scalar primitives of the arithmetic modes.  exact / fma: IEEE divide and square root (the compiler's correctly
+// rounded expansions); fast: the hardware approximations v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp).
+PT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PT_DEV float rcp_(float x) { return kFast ? __builtin_amdgcn_rcpf(x) : 1.0f / x; }
+PT_DEV float div_(float a, float b) { return kFast ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+PT_DEV float sqrt_(float x) { return kFast ? __builtin_amdgcn_sqrtf(x) : __builtin_sqrtf(x); }
+PT_DEV float dot(f3 a, f3 b) {
+  if (kFast) return fma_(a.x, b.x, fma_(a.y, b.y, a.z * b.z));
+  return (a.x * b.x + a.y * b.y) + a.z * b.z;
+}
 PT_DEV f3 cross(f3 x, f3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
-PT_DEV f3 normalize(f3 v) { return scl(v, 1.0f / __builtin_sqrtf(dot(v, v))); }
-PT_DEV float length(f3 v) { return __builtin_sqrtf(dot(v, v)); }
+PT_DEV f3 normalize(f3 v) { return scl(v, kFast ? __builtin_amdgcn_rsqf(dot(v, v)) : 1.0f / __builtin_sqrtf(dot(v, v))); }
+PT_DEV float length(f3 v) { return sqrt_(dot(v, v)); }
+PT_DEV f3 madd(f3 a, float s, f3 b) {  // a * s + b
+  if (kFast) return mk(fma_(a.x, s, b.x), fma_(a.y, s, b.y), fma_(a.z, s, b.z));
+  return add(scl(a, s), b);
+}
 
-// vec3(m * vec4(v, w)) in GLM order: (m0*v0 + m1*v1) + (m2*v2 + m3*w); m is [c*3+r].
-PT_DEV f3 mulMV(const float* m, f3 v, float w) {
+// vec3(m * vec4(v, w)) in GLM order: (m0*v0 + m1*v1) + (m2*v2 + m3*w); m is [c*3+r].  W is 0 (direction) or 1
+// (point); fast: one multiply + FMA chain per row.
+template <int W>
+PT_DEV f3 mulMV(const float* m, f3 v) {
   f3 r;
+  if (kFast) {
+    r.x = fma_(m[0], v.x, fma_(m[3], v.y, W ? fma_(m[6], v.z, m[9]) : m[6] * v.z));
+    r.y = fma_(m[1], v.x, fma_(m[4], v.y, W ? fma_(m[7], v.z, m[10]) : m[7] * v.z));
+    r.z = fma_(m[2], v.x, fma_(m[5], v.y, W ? fma_(m[8], v.z, m[11]) : m[8] * v.z));
+    return r;
+  }
+  const float w = (float)W;
   r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * w);
   r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * w);
   r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11] * w);
@@ -207,8 +259,8 @@ struct HitRec {
 // value per geom: computed once per block by the primary kernel with this same mulMV).
 template <int TYPE, bool QO = false>
 PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& point, f3& normal, f3 qo_pre = f3{0.f, 0.f, 0.f}) {
-  const f3 qo = QO ? qo_pre : mulMV(G->inv, ro_w, 1.0f);
-  const f3 qd = normalize(mulMV(G->inv, rd_w, 0.0f));
+  const f3 qo = QO ? qo_pre : mulMV<1>(G->inv, ro_w);
+  const f3 qd = normalize(mulMV<0>(G->inv, rd_w));
   const bool is_box = TYPE < 0 ? (G->type == 1) : (TYPE == 1);
   float t;
   f3 nobj = mk(0.f, 0.f, 0.f);
@@ -221,8 +273,15 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
     const float qov[3] = {qo.x, qo.y, qo.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const float t1 = (-0.5f - qov[a]) / qdv[a];
-      const float t2 = (+0.5f - qov[a]) / qdv[a];
+      float t1, t2;
+      if (kFast) {  // one reciprocal per axis; the subtract-then-multiply form keeps 0-direction axes at +-inf
+        const float r = __builtin_amdgcn_rcpf(qdv[a]);
+        t1 = (-0.5f - qov[a]) * r;
+        t2 = (+0.5f - qov[a]) * r;
+      } else {
+        t1 = (-0.5f - qov[a]) / qdv[a];
+        t2 = (+0.5f - qov[a]) / qdv[a];
+      }
       const float ta = t1 < t2 ? t1 : t2;  // glm::min
       const float tb = t1 > t2 ? t1 : t2;  // glm::max
       const int c = 1 + 2 * a + (t2 < t1 ? 1 : 0);  // n[xyz] = t2 < t1 ? +1 : -1
@@ -244,13 +303,12 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
     ncode = tmin_c;
   } else {
     // radius .5 → powf(.5, 2) = .25
-    const float vDotDirection = dot(qo, qd);
-    const float radicand = vDotDirection * vDotDirection - (dot(qo, qo) - 0.25f);
-    if (radicand < 0.f) return -1.0f;
-    const float squareRoot = __builtin_sqrtf(radicand);
-    const float firstTerm = -vDotDirection;
-    const float t1 = firstTerm + squareRoot;
-    const float t2 = firstTerm - squareRoot;
+    const float along = dot(qo, qd);
+    const float disc = kFast ? fma_(along, along, 0.25f - dot(qo, qo)) : along * along - (dot(qo, qo) - 0.25f);
+    if (disc < 0.f) return -1.0f;
+    const float root = sqrt_(disc);
+    const float t1 = -along + root;
+    const float t2 = -along - root;
     if (t1 < 0.f && t2 < 0.f) return -1.0f;
     if (t1 > 0.f && t2 > 0.f) {
       t = t2 < t1 ? t2 : t1;  // min(t1, t2)
@@ -259,14 +317,15 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
       flip = true;            // !outside → normal negated
     }
   }
-  // getPointOnRay (intersections.h:27-29): origin + (t - .0001f) * normalize(direction)
-  const f3 objp = add(qo, scl(normalize(qd), t - .0001f));
+  // getPointOnRay (intersections.h:27-29): origin + (t - .0001f) * normalize(direction); qd is already a unit
+  // vector, so the fast mode does not normalise it a second time
+  const f3 objp = kFast ? madd(qd, t - .0001f, qo) : add(qo, scl(normalize(qd), t - .0001f));
   if (!is_box) nobj = objp;
-  point = mulMV(G->xf, objp, 1.0f);
+  point = mulMV<1>(G->xf, objp);
   if (is_box) {
     normal = mk(G->box_normal[ncode][0], G->box_normal[ncode][1], G->box_normal[ncode][2]);  // precomputed, exact
   } else {
-    normal = normalize(mulMV(G->invT, nobj, 0.0f));
+    normal = normalize(mulMV<0>(G->invT, nobj));
     if (flip) normal = neg(normal);
   }
   return length(sub(ro_w, point));
@@ -279,39 +338,36 @@ PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& po
 struct RayInv {
   float ix, iy, iz;
   bool sx, sy, sz;
+  float nx, ny, nz;  // fast mode: -origin * reciprocal, so that (b - o) / d is one FMA per plane
 };
-PT_DEV RayInv ray_inv(f3 d) {
+// Reciprocal direction of a ray starting at o.  fast: |d| is clamped to >= 1e-20 so that the reciprocal stays finite
+// (an axis-parallel ray would otherwise produce inf - inf in the FMA form of the slab test).
+PT_DEV RayInv ray_inv(f3 d, f3 o) {
   RayInv r;
-  r.ix = 1.0f / d.x, r.iy = 1.0f / d.y, r.iz = 1.0f / d.z;
+  if (kFast) {
+    const float dx = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), 1e-20f), d.x);
+    const float dy = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), 1e-20f), d.y);
+    const float dz = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), 1e-20f), d.z);
+    r.ix = __builtin_amdgcn_rcpf(dx), r.iy = __builtin_amdgcn_rcpf(dy), r.iz = __builtin_amdgcn_rcpf(dz);
+  } else {
+    r.ix = 1.0f / d.x, r.iy = 1.0f / d.y, r.iz = 1.0f / d.z;
+  }
   r.sx = r.ix < 0.0f, r.sy = r.iy < 0.0f, r.sz = r.iz < 0.0f;
+  r.nx = -o.x * r.ix, r.ny = -o.y * r.iy, r.nz = -o.z * r.iz;
   return r;
 }
-PT_DEV bool slab(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
-  const float t0x = ((ri.sx ? hix : lox) - o.x) * ri.ix;
-  const float t1x = ((ri.sx ? lox : hix) - o.x) * ri.ix;
-  const float t0y = ((ri.sy ? hiy : loy) - o.y) * ri.iy;
-  const float t1y = ((ri.sy ? loy : hiy) - o.y) * ri.iy;
-  const float t0z = ((ri.sz ? hiz : loz) - o.z) * ri.iz;
-  const float t1z = ((ri.sz ? loz : hiz) - o.z) * ri.iz;
-  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
-  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
-  return !(tmax <= tmin);
-}
-
-// slab() on a box given relative to the ray origin (lo - o, hi - o precomputed with the same subtraction).
-PT_DEV bool slab_rel(const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
-  const float t0x = (ri.sx ? hix : lox) * ri.ix;
-  const float t1x = (ri.sx ? lox : hix) * ri.ix;
-  const float t0y = (ri.sy ? hiy : loy) * ri.iy;
-  const float t1y = (ri.sy ? loy : hiy) * ri.iy;
-  const float t0z = (ri.sz ? hiz : loz) * ri.iz;
-  const float t1z = (ri.sz ? loz : hiz) * ri.iz;
-  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
-  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
-  return !(tmax <= tmin);
+// Slab test from the six plane distances (near/far per axis by min/max): the fast-mode form.
+PT_DEV bool slab_planes(float ax, float bx, float ay, float by, float az, float bz, float& tn) {
+  const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+  const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+  tn = __builtin_fmaxf(t0, 0.0f);
+  return !(t1 <= tn);
 }
 // slab() that also returns the entry distance (for the closer-hit cull of the subtree scans).
 PT_DEV bool slab_t(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn) {
+  if (kFast)
+    return slab_planes(fma_(lox, ri.ix, ri.nx), fma_(hix, ri.ix, ri.nx), fma_(loy, ri.iy, ri.ny), fma_(hiy, ri.iy, ri.ny),
+                       fma_(loz, ri.iz, ri.nz), fma_(hiz, ri.iz, ri.nz), tn);
   const float t0x = ((ri.sx ? hix : lox) - o.x) * ri.ix;
   const float t1x = ((ri.sx ? lox : hix) - o.x) * ri.ix;
   const float t0y = ((ri.sy ? hiy : loy) - o.y) * ri.iy;
@@ -321,6 +377,26 @@ PT_DEV bool slab_t(f3 o, const RayInv& ri, float lox, float loy, float loz, floa
   const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
   const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
   tn = tmin;
+  return !(tmax <= tmin);
+}
+PT_DEV bool slab(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+  float tn;
+  return slab_t(o, ri, lox, loy, loz, hix, hiy, hiz, tn);
+}
+// slab() on a box given relative to the ray origin (lo - o, hi - o precomputed with the same subtraction).
+PT_DEV bool slab_rel(const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+  if (kFast) {
+    float tn;
+    return slab_planes(lox * ri.ix, hix * ri.ix, loy * ri.iy, hiy * ri.iy, loz * ri.iz, hiz * ri.iz, tn);
+  }
+  const float t0x = (ri.sx ? hix : lox) * ri.ix;
+  const float t1x = (ri.sx ? lox : hix) * ri.ix;
+  const float t0y = (ri.sy ? hiy : loy) * ri.iy;
+  const float t1y = (ri.sy ? loy : hiy) * ri.iy;
+  const float t0z = (ri.sz ? hiz : loz) * ri.iz;
+  const float t1z = (ri.sz ? loz : hiz) * ri.iz;
+  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
+  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
   return !(tmax <= tmin);
 }
 
@@ -399,6 +475,7 @@ PT_DEV void steal_step(Walker& w, uint32_t& pend, uint32_t xm, bool idle, unsign
     w.o = so;
     w.ri.ix = si.x, w.ri.iy = si.y, w.ri.iz = si.z;
     w.ri.sx = si.x < 0.0f, w.ri.sy = si.y < 0.0f, w.ri.sz = si.z < 0.0f;
+    w.ri.nx = -so.x * si.x, w.ri.ny = -so.y * si.y, w.ri.nz = -so.z * si.z;
   }
 }
 // Legacy traversal (kept for A/B measurements, PtOptions flag): one lane walks the threaded
@@ -409,7 +486,7 @@ PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const pt
   h.geom = -1;
   h.n = mk(0.f, 0.f, 0.f);
   h.p = mk(0.f, 0.f, 0.f);
-  const RayInv ri = ray_inv(d);
+  const RayInv ri = ray_inv(d, o);
   int i = 0;
   while (true) {
     int g = -1;
@@ -560,7 +637,7 @@ template <bool CAM, bool QO = CAM>
 PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull,
                         unsigned long long top_xor, const float* qo_tab = nullptr) {
-  const RayInv ri = ray_inv(d);
+  const RayInv ri = ray_inv(d, o);
   w.best[lane] = kNoHit;
   int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
   uint32_t pend = 0;   // per lane: top entries that are subtrees and whose box this ray passes
@@ -776,7 +853,8 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
   if (depth > 3) {  // Russian roulette
     const float q = __builtin_fmaxf(mcolor.x, __builtin_fmaxf(mcolor.y, mcolor.z));
     if (rng.u01() > q) return bo;
-    s.c = mk(s.c.x / q, s.c.y / q, s.c.z / q);
+    if (kFast) s.c = scl(s.c, __builtin_amdgcn_rcpf(q));
+    else s.c = mk(s.c.x / q, s.c.y / q, s.c.z / q);
   }
   const float reflectivity = m->reflective;
   bo.roughness = 1.0f - m->refractive;
@@ -793,7 +871,35 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
   s.alive = (depth + 1) < trace_depth;
   return bo;
 }
+// Fast-mode direction sampling: the same draws and the same formulas, evaluated in float only.
+//   v_sin_f32 / v_cos_f32 take their argument in revolutions, so sin(2*pi*u) is one instruction on u itself;
+//   diffuse: cos(theta) = sqrt(1 - u1) =: s and sin(theta) = sin(acos(s)) = sqrt(1 - s*s) (one FMA keeps 1 - s*s exact
+//   to one rounding), so neither acos nor a sincos of theta is evaluated;
+//   specular: angle = roughness*u1*pi/2 = roughness*u1/4 revolutions.
+PT_DEV void shade_bounce_fast(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
+  MinStd rng(1u);
+  rng.x = bo.rng_x;
+  const bool spec = bo.kind == 1;
+  const float r1 = rng.u01(), r2 = rng.u01(), r3 = rng.u01();
+  const f3 refl = madd(hn, -2.0f * dot(s.d, hn), s.d);
+  const f3 f = spec ? refl : hn;
+  const float rev = bo.roughness * r1 * 0.25f;
+  const float ct = __builtin_amdgcn_sqrtf(1.0f - r1);
+  const float st = __builtin_amdgcn_sqrtf(__builtin_fmaxf(fma_(-ct, ct, 1.0f), 0.0f));
+  const float sX = spec ? __builtin_amdgcn_sinf(rev) : st;
+  const float cX = spec ? __builtin_amdgcn_cosf(rev) : ct;
+  const float c1 = __builtin_amdgcn_cosf(r2);
+  const float s2 = __builtin_amdgcn_sinf(spec ? r3 : r2);
+  const float x = sX * c1, z = sX * s2, y = cX;
+  f3 tangent, bitangent;
+  local_frame(f, tangent, bitangent);
+  const f3 pert = normalize(madd(tangent, x, madd(f, y, scl(bitangent, z))));
+  const bool perturb = !spec || bo.roughness > 0.0f;
+  s.o = madd(hn, 0.001f, hp);
+  s.d = perturb ? pert : refl;
+}
 PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
+  if (kFast) return shade_bounce_fast(bo, hn, hp, s);
   // The specular branch (pathtrace.cu:402-422) and the diffuse branch (:424-435, :225-238) have the
   // same shape — a frame around an axis f, three trigonometric evaluations, normalize(t*x + f*y + b*z)
   // — so both are evaluated by ONE instruction stream with per-lane operands instead of two divergent
@@ -843,11 +949,11 @@ struct Reservation {
   unsigned long long live;
   int base;
 };
-PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int slot, int64_t FS, float* __restrict__ final_rgb,
+PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int slot, float4* __restrict__ final_rgba,
                                       int32_t* __restrict__ counter, int lane) {
-  if (valid && !s.alive) {
-    final_rgb[slot] = s.c.x, final_rgb[FS + slot] = s.c.y, final_rgb[2 * FS + slot] = s.c.z;
-  }
+  // one 16-B store per retired sample: retirements are scattered over the batch, and three 4-B stores into three
+  // planes dirtied three partially filled lines per sample (PMC round 1: 59 B written per 12 B retired)
+  if (valid && !s.alive) final_rgba[slot] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
   Reservation r;
   r.live = __ballot(valid && s.alive);
   r.base = 0;
@@ -872,7 +978,7 @@ PT_DEV void emit_survivors(const Reservation& r, bool alive, const ShadeIO& s, i
 __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                   const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
                                                   ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                                                  float* __restrict__ final_rgb) {
+                                                  float4* __restrict__ final_rgba) {
   extern __shared__ float4 lds_raw[];
   stage16(lds_raw, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
   uint32_t* ihash = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_raw) + ((sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15));
@@ -885,7 +991,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t S = in.stride, HS = hits.stride;
-  const int64_t FS = (int64_t)b.K * b.N;
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
   // inputs of one path; the next group's are loaded (branch-free, index clamped into the queue's own
@@ -927,7 +1032,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
       divmod(slot, b.N, inv_n, k, p);
       bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, b, depth, k), global_pixel(b, p), cur.ht, cur.hmat, s);
     }
-    const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, cur.hn, cur.hp, s);
     emit_survivors(res, alive, s, slot, qbase, out);
@@ -982,7 +1087,7 @@ PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__
   const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
   f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
   float t = -1.0f;
-  if (!(c.debug & 4)) t = geom_test<-1>(G, ro, rd, pt, nrm);  // cube / sphere decided per lane; shared pre and post parts
+  if (!(kAblate && (c.debug & 4))) t = geom_test<-1>(G, ro, rd, pt, nrm);  // cube / sphere decided per lane; shared pre and post parts
   const uint32_t tb = __float_as_uint(t);
   if (valid && t > 0.f && tb < 0x7f7fffffu) {
     const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
@@ -1021,7 +1126,7 @@ template <bool SUB>
 PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
                          unsigned long long top_xor) {
-  const RayInv ri = ray_inv(d);
+  const RayInv ri = ray_inv(d, o);
   {
     float* ray = c.ray + par * 6 * 64 + lane;  // this group's rays, read back by the primitive-test chunks
     ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
@@ -1083,7 +1188,7 @@ struct Pending {
 // Shading + retirement + compaction of a pending group from its resolved hit keys/records.
 PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
                           const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
-                          int depth, float inv_n, int64_t FS, float* __restrict__ final_rgb,
+                          int depth, float inv_n, float4* __restrict__ final_rgba,
                           int32_t* __restrict__ counter, int64_t qbase, ptd::PathBuf out, int lane) {
   const unsigned long long best = cy.best[pg.par * 64 + lane];
   const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1109,9 +1214,9 @@ PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __
     divmod(pg.slot, b.N, inv_n, k, p);
     bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, b, depth, k), global_pixel(b, p), ht, hmat, s);
   }
-  const Reservation res = retire_and_reserve(pg.valid, s, pg.slot, FS, final_rgb, counter, lane);
+  const Reservation res = retire_and_reserve(pg.valid, s, pg.slot, final_rgba, counter, lane);
   const bool alive = pg.valid && s.alive;
-  if (alive && !(b.debug & 8)) shade_bounce(bo, hn, hp, s);
+  if (alive && !(kAblate && (b.debug & 8))) shade_bounce(bo, hn, hp, s);
   emit_survivors(res, alive, s, pg.slot, qbase, out);
 }
 
@@ -1125,14 +1230,13 @@ PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __
 template <bool TABLES_IN_LDS>
 __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
                                                     int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
-                                                    ptd::PathBuf out, float* __restrict__ final_rgb) {
+                                                    ptd::PathBuf out, float4* __restrict__ final_rgba) {
   extern __shared__ float4 lds_raw[];
   char* lds = reinterpret_cast<char*>(lds_raw);
   const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
   stage16(lds + nb_top, sc.mats, nb_mats);
-  const float4* top = reinterpret_cast<const float4*>(lds);
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
   const ptd::Node* nodes = sc.nodes;
   const ptd::Geom* geoms = sc.geoms;
@@ -1160,7 +1264,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
       cam_top[2 * e + 1] = make_float4(t.bmax[1] - cp.y, t.bmax[2] - cp.z, __int_as_float(t.idx), __int_as_float(t.link));
     }
     for (int gi = threadIdx.x; TABLES_IN_LDS && gi < sc.num_geoms; gi += blockDim.x) {
-      const f3 q = mulMV(sc.geoms[gi].inv, cp, 1.0f);
+      const f3 q = mulMV<1>(sc.geoms[gi].inv, cp);
       cam_qo[3 * gi] = q.x, cam_qo[3 * gi + 1] = q.y, cam_qo[3 * gi + 2] = q.z;
     }
   }
@@ -1189,7 +1293,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     }
     cnt0[(size_t)q * qs.cnt_stride] = (int32_t)n;
   }
-  const int64_t FS = total;
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N, inv_w = 1.0f / (float)cam.res_x;
   const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
@@ -1204,7 +1307,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
     // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
-    const bool near_scene = __ballot(valid && slab(o, ray_inv(d), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+    const bool near_scene = __ballot(valid && slab(o, ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
     if (near_scene) trace_group<true, TABLES_IN_LDS>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
     else w.best[lane] = kNoHit;
@@ -1229,7 +1332,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, b, 0, k), p, ht, hmat, s);
     }
-    const Reservation res = retire_and_reserve(valid, s, slot, FS, final_rgb, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
     emit_survivors(res, alive, s, slot, qbase, out);
@@ -1246,7 +1349,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
 template <bool TABLES_IN_LDS>
 __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                    const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
-                                                   ptd::PathBuf in, ptd::PathBuf out, float* __restrict__ final_rgb) {
+                                                   ptd::PathBuf in, ptd::PathBuf out, float4* __restrict__ final_rgba) {
   extern __shared__ float4 lds_raw[];
   char* lds = reinterpret_cast<char*>(lds_raw);
   const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
@@ -1279,7 +1382,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t S = in.stride;
-  const int64_t FS = (int64_t)b.K * b.N;
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
   struct In {
@@ -1311,7 +1413,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     carry_search<!TABLES_IN_LDS>(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
     if (pg.any) {  // the previous group: all of its candidates are resolved once the ring has passed its mark
       carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-      shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
+      shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, qbase, out, lane);
     }
     pg.d = cur.d;
     pg.c = cur.c;
@@ -1323,7 +1425,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
   }
   if (pg.any) {
     carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-    shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, FS, final_rgb, counter, qbase, out, lane);
+    shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, qbase, out, lane);
   }
 }
 
@@ -1355,29 +1457,23 @@ __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trac
 }
 
 // ───────────────────────────── gather / stats / preview ────────────────────
-__global__ __launch_bounds__(kBlock) void k_gather(BatchInfo b, const float* __restrict__ final_rgb,
+__global__ __launch_bounds__(kBlock) void k_gather(BatchInfo b, const float4* __restrict__ final_rgba,
                                                    float* __restrict__ image) {
-  const int64_t FS = (int64_t)b.K * b.N;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < b.N; p += gridDim.x * blockDim.x) {
     float r = image[3 * (int64_t)p], g = image[3 * (int64_t)p + 1], bl = image[3 * (int64_t)p + 2];
-    // iteration order, like successive finalGather launches; loads are issued eight iterations at a time so
-    // that 24 of them are in flight per lane, the adds stay strictly sequential (float sums are order-dependent)
+    // iteration order, like successive finalGather launches; loads are issued eight iterations at a time (eight
+    // 16-B records in flight per lane), the adds stay strictly sequential (float sums are order-dependent)
     int k = 0;
     for (; k + 8 <= b.K; k += 8) {
-      float vr[8], vg[8], vb[8];
+      float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t s = (int64_t)(k + u) * b.N + p;
-        vr[u] = final_rgb[s], vg[u] = final_rgb[FS + s], vb[u] = final_rgb[2 * FS + s];
-      }
+      for (int u = 0; u < 8; ++u) v[u] = final_rgba[(int64_t)(k + u) * b.N + p];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) r += vr[u], g += vg[u], bl += vb[u];
+      for (int u = 0; u < 8; ++u) r += v[u].x, g += v[u].y, bl += v[u].z;
     }
     for (; k < b.K; ++k) {
-      const int64_t s = (int64_t)k * b.N + p;
-      r += final_rgb[s];
-      g += final_rgb[FS + s];
-      bl += final_rgb[2 * FS + s];
+      const float4 v = final_rgba[(int64_t)k * b.N + p];
+      r += v.x, g += v.y, bl += v.z;
     }
     image[3 * (int64_t)p] = r, image[3 * (int64_t)p + 1] = g, image[3 * (int64_t)p + 2] = bl;
   }
@@ -1421,22 +1517,48 @@ __global__ __launch_bounds__(kBlock) void k_preview(int n, int iterations, const
   }
 }
 
+// saveImage (main.cpp:86-107) + image::savePNG's conversion (image.cpp:22-39) on the device, for tiles made of whole
+// image rows: tile pixel p = x + ty*W becomes three bytes at the x-mirrored position (W - 1 - x) + ty*W of its row,
+// each (unsigned char)(clamp(sum / samples, 0, 1) * 255) — truncation, no gamma, NaN -> 0 like pt_image.cpp's to_u8.
+// Write-out then moves 3 B per pixel over PCIe / xGMI instead of 12.
+__global__ __launch_bounds__(kBlock) void k_save_u8(int n, int width, float samples, const float* __restrict__ image,
+                                                    uint8_t* __restrict__ rgb8) {
+  const float inv_w = 1.0f / (float)width;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    int ty, x;
+    divmod(p, width, inv_w, ty, x);
+    uint8_t* dst = rgb8 + 3 * ((int64_t)ty * width + (width - 1 - x));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = image[3 * (int64_t)p + c] / samples;  // IEEE divide in every mode: bytes equal the host writer's
+      float m = v > 0.0f ? v : 0.0f;
+      m = m < 1.0f ? m : 1.0f;
+      dst[c] = (uint8_t)(m * 255.f);
+    }
+  }
+}
+
 inline int round16(int x) { return (x + 15) & ~15; }
 
-}  // namespace
-
 // ───────────────────────────── launch wrappers ─────────────────────────────
-static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false);
-static int g_lds_table_bytes = kLdsTableBytes;
+int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false) {
+  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
+              kIterHashMax * 4;
+  if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
+  if (primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + (in_lds ? round16(sc.num_geoms * 12) : 0);  // camera-relative copies
+  return bytes;
+}
+int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
+bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
 // The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
-static bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
-void set_lds_table_limit(const SceneTables& sc, int bytes) { g_lds_table_bytes = leaves_fit_top(sc) ? bytes : -1; }
+bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
 // Stage the scene tables in LDS only if every leaf is a top-list entry and staging does not cost the dominant kernel a
 // resident block per CU: measured on
 // random scenes at 1080p, 156 geoms (52 KB of tables, 1 block/CU) ran at 2.2 Gsamples/s from LDS and 4.5 from
 // global memory / L2 (4 blocks/CU); 26 geoms (8 KB) are equal either way; cornell's 2.3 KB keep all 4 blocks.
-void auto_lds_table_limit(const SceneTables& sc) {
-  const int tbl = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
+int lds_table_limit(const SceneTables& sc, int forced_bytes) {
+  if (forced_bytes >= 0) return leaves_fit_top(sc) ? forced_bytes : -1;
+  const int tbl = table_bytes(sc);
   int with = 0, without = 0;
   if (tbl <= kLdsTableBytes && leaves_fit_top(sc) &&
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2)) != hipSuccess)
@@ -1444,33 +1566,34 @@ void auto_lds_table_limit(const SceneTables& sc) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2)) != hipSuccess)
     without = 1;
   (void)hipGetLastError();
-  g_lds_table_bytes = (with >= without && with > 0) ? tbl : -1;
+  return (with >= without && with > 0) ? tbl : -1;
 }
 
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
   int n = 0;
   hipError_t e = hipSuccess;
-  const int tbl = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
+  const int tbl = table_bytes(sc);
+  const bool in_lds = tables_in_lds(sc);
   switch (id) {
     case kGenerate:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_generate, kBlock, 0);
       break;
     case kIntersect:
-      if (tbl <= g_lds_table_bytes)
+      if (in_lds)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true>, kBlock, round16(tbl) + kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
       else
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false>, kBlock, kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
       break;
     case kIntersectLegacy:
-      if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true>, kBlock, round16(tbl));
+      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true>, kBlock, round16(tbl));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false>, kBlock, 0);
       break;
     case kPrimary:
-      if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
+      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kBounce:
-      if (tbl <= g_lds_table_bytes) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2));
+      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2));
       break;
     case kShade:
@@ -1488,8 +1611,8 @@ void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const Batc
 
 void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
                       ptd::PathBuf paths, ptd::HitBuf hits, bool legacy) {
-  const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
-  const bool in_lds = bytes <= g_lds_table_bytes;
+  const int bytes = table_bytes(sc);
+  const bool in_lds = tables_in_lds(sc);
   if (legacy) {
     if (in_lds) hipLaunchKernelGGL(k_intersect_legacy<true>, dim3(grid), dim3(kBlock), round16(bytes), s, sc, qs, cnt_in, paths, hits);
     else hipLaunchKernelGGL(k_intersect_legacy<false>, dim3(grid), dim3(kBlock), 0, s, sc, qs, cnt_in, paths, hits);
@@ -1500,42 +1623,32 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
   else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), wave_lds, s, sc, qs, cnt_in, paths, hits);
 }
 
-static int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary) {
-  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
-              kIterHashMax * 4;
-  if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
-  if (primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + (in_lds ? round16(sc.num_geoms * 12) : 0);  // camera-relative copies
-  return bytes;
-}
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
-                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float* final_rgb) {
-  const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
-  const bool in_lds = bytes <= g_lds_table_bytes;
-  if (in_lds) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgb);
+                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float4* final_rgba) {
+  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
 }
 
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
-                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float* final_rgb) {
-  const int bytes = sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom);
-  const bool in_lds = bytes <= g_lds_table_bytes;
-  if (in_lds) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
-  else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgb);
+                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba) {
+  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
+  else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
 }
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                  float* final_rgb) {
+                  float4* final_rgba) {
   const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kIterHashMax * 4;
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
-                     final_rgb);
+                     final_rgba);
 }
 
-void launch_gather(hipStream_t s, const BatchInfo& b, const float* final_rgb, float* image_rgb) {
-  int grid = (b.N + kBlock - 1) / kBlock;
-  if (grid > 4096) grid = 4096;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlock), 0, s, b, final_rgb, image_rgb);
+int flat_grid(int n, int cap) {
+  int grid = (n + kBlock - 1) / kBlock;
+  return grid > cap ? cap : (grid < 1 ? 1 : grid);
+}
+void launch_gather(hipStream_t s, const BatchInfo& b, const float4* final_rgba, float* image_rgb) {
+  hipLaunchKernelGGL(k_gather, dim3(flat_grid(b.N, 4096)), dim3(kBlock), 0, s, b, final_rgba, image_rgb);
 }
 
 void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count,
@@ -1544,20 +1657,34 @@ void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int 
 }
 
 void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba) {
-  int grid = (n + kBlock - 1) / kBlock;
-  if (grid > 4096) grid = 4096;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(k_preview, dim3(grid), dim3(kBlock), 0, s, n, iterations, image_rgb, rgba);
+  hipLaunchKernelGGL(k_preview, dim3(flat_grid(n, 4096)), dim3(kBlock), 0, s, n, iterations, image_rgb, rgba);
+}
+
+void launch_save_u8(hipStream_t s, int n, int width, float samples, const float* image_rgb, uint8_t* rgb8) {
+  hipLaunchKernelGGL(k_save_u8, dim3(flat_grid(n, 4096)), dim3(kBlock), 0, s, n, width, samples, image_rgb, rgb8);
 }
 
 void launch_shade_stage(hipStream_t s, const SceneTables& sc, int trace_depth, int depth, int n, const int32_t* iter,
                         const int32_t* pixel, ptd::HitBuf hits, ptd::PathBuf paths, int32_t* alive) {
-  int grid = (n + kBlock - 1) / kBlock;
-  if (grid > 2048) grid = 2048;
-  if (grid < 1) grid = 1;
   const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat));
-  hipLaunchKernelGGL(k_shade_stage, dim3(grid), dim3(kBlock), bytes, s, sc, trace_depth, depth, n, iter, pixel, hits,
+  hipLaunchKernelGGL(k_shade_stage, dim3(flat_grid(n, 2048)), dim3(kBlock), bytes, s, sc, trace_depth, depth, n, iter, pixel, hits,
                      paths, alive);
 }
+
+const KernelApi kApi = {
+#if PT_ARITH == 0
+    "exact",
+#elif PT_ARITH == 1
+    "fma",
+#else
+    "fast",
+#endif
+    launch_generate, launch_primary, launch_bounce, launch_intersect, launch_shade, launch_gather, launch_count_stats,
+    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu};
+
+}  // namespace
+}  // namespace PT_NS
+
+const KernelApi* PT_API_FN() { return &PT_NS::kApi; }
 
 }  // namespace ptk

@@ -1,34 +1,56 @@
 // pt_render — headless driver: what the reference's main() / runCuda() / saveImage()
 // (src/main.cpp:34-156) do without the GLFW window: load a scene file, run
-// state.iterations iterations through pathtraceInit/pathtrace/pathtraceFree, write
-// <FILE>.<spp>samp.png.  Flags exist only because the reference takes resolution,
-// iteration count and depth from the scene file (scene.cpp:103-114).
+// state.iterations iterations, write the PNG saveImage() would write.  Flags exist only because
+// the reference takes resolution, iteration count and depth from the scene file (scene.cpp:103-114).
 //
 //   pt_render SCENE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm]
+//                       [--arith exact|fma|fast] [--gpus K] [--stamp]
+//
+// Without --gpus the run goes through the pathtrace.h-compatible shim (pathtraceInit / pathtrace per
+// iteration / pathtraceFree), i.e. the code path a reference main.cpp would take.  With --gpus K (K >= 1;
+// K = 0: all visible devices) it goes through pt_group_*: K devices in this one process, row-interleaved
+// tiles, one grouped RCCL send/recv at write-out (BASELINE config 4), PNG bytes converted on the devices.
+// Output name: PREFIX.<spp>samp.png, or with --stamp the reference's own
+// <FILE>.<UTC start time>.<spp>samp.png (main.cpp:99-102).
+#include <hip/hip_runtime.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/pathtrace_amd.hpp"
 #include "pt_scene.h"
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::printf("Usage: %s SCENEFILE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm]\n", argv[0]);
+    std::printf("Usage: %s SCENEFILE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] "
+                "[--arith exact|fma|fast] [--gpus K] [--stamp]\n", argv[0]);
     return 1;
   }
-  int rw = 0, rh = 0, spp = 0, depth = 0;
-  bool pfm = false;
+  int rw = 0, rh = 0, spp = 0, depth = 0, gpus = -1, arith = PT_ARITH_EXACT;
+  bool pfm = false, stamp = false;
   std::string out;
   for (int i = 2; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--res") && i + 1 < argc) std::sscanf(argv[++i], "%dx%d", &rw, &rh);
     else if (!std::strcmp(argv[i], "--spp") && i + 1 < argc) spp = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--depth") && i + 1 < argc) depth = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+    else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--pfm")) pfm = true;
-    else {
+    else if (!std::strcmp(argv[i], "--stamp")) stamp = true;
+    else if (!std::strcmp(argv[i], "--arith") && i + 1 < argc) {
+      const char* a = argv[++i];
+      if (!std::strcmp(a, "exact")) arith = PT_ARITH_EXACT;
+      else if (!std::strcmp(a, "fma")) arith = PT_ARITH_FMA;
+      else if (!std::strcmp(a, "fast")) arith = PT_ARITH_FAST;
+      else {
+        std::fprintf(stderr, "unknown arithmetic mode %s\n", a);
+        return 1;
+      }
+    } else {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
       return 1;
     }
@@ -46,24 +68,77 @@ int main(int argc, char** argv) {
   scene->applyInitialCameraState();
   const int W = scene->state.camera.resolution[0], H = scene->state.camera.resolution[1];
   const int iters = (int)scene->state.iterations;
-
-  GuiDataContainer gui;
-  InitDataContainer(&gui);
-  pathtraceFree();  // main.cpp:134 frees before the first init
-  pathtraceInit(scene);
-  const auto t0 = std::chrono::high_resolution_clock::now();
-  for (int it = 1; it <= iters; ++it) pathtrace(nullptr, 0, it);  // main.cpp:138-149
-  pathtraceSyncImage();
-  const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-  std::printf("%dx%d, %d spp, depth %d: %.3f s, %.2f Msamples/s\n", W, H, iters, scene->state.traceDepth, secs,
-              (double)W * H * iters / secs / 1e6);
   if (out.empty()) out = scene->state.imageName;
-  const std::string base = out + "." + std::to_string(iters) + "samp";
-  if (pt_save_png((base + ".png").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
-    std::printf("Saved %s.png.\n", base.c_str());
-  if (pfm && pt_save_pfm((base + ".pfm").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
-    std::printf("Saved %s.pfm.\n", base.c_str());
-  pathtraceFree();
+  std::string base = out + "." + std::to_string(iters) + "samp";
+  if (stamp) {
+    char buf[1024];
+    pt_output_basename(out.c_str(), iters, buf, sizeof buf);
+    base = buf;
+  }
+
+  double secs = 0;
+  if (gpus < 0) {
+    // the reference's call sequence (main.cpp:133-152) through the pathtrace.h shim
+    GuiDataContainer gui;
+    InitDataContainer(&gui);
+    pathtraceFree();  // main.cpp:134 frees before the first init
+    pathtraceSetArith(arith);
+    pathtraceInit(scene);
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (int it = 1; it <= iters; ++it) pathtrace(nullptr, 0, it);  // main.cpp:138-149
+    pathtraceSyncImage();
+    secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    std::printf("%dx%d, %d spp, depth %d: %.3f s, %.2f Msamples/s\n", W, H, iters, scene->state.traceDepth, secs,
+                (double)W * H * iters / secs / 1e6);
+    if (pt_save_png((base + ".png").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
+      std::printf("Saved %s.png.\n", base.c_str());
+    if (pfm && pt_save_pfm((base + ".pfm").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
+      std::printf("Saved %s.pfm.\n", base.c_str());
+    pathtraceFree();
+  } else {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      std::fprintf(stderr, "no HIP device\n");
+      return 1;
+    }
+    if (gpus == 0) gpus = ndev;
+    if (gpus > ndev) {
+      std::fprintf(stderr, "--gpus %d but only %d device(s) visible\n", gpus, ndev);
+      return 1;
+    }
+    std::vector<int> devices(gpus);
+    for (int i = 0; i < gpus; ++i) devices[i] = i;
+    PtOptions opt{};
+    opt.arith = arith;
+    const PtSceneDesc desc = scene->desc();
+    PtGroup* grp = nullptr;
+    if (pt_group_create(&desc, &opt, devices.data(), gpus, &grp)) {
+      std::fprintf(stderr, "HIP error (pt_group_create): %s\n", pt_last_error());
+      return EXIT_FAILURE;
+    }
+    std::vector<uint8_t> rgb8((size_t)W * H * 3);
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    int rc = pt_group_render(grp, 1, iters);
+    if (!rc) rc = pt_group_gather_u8(grp, (float)iters, rgb8.data());  // the write-out gather: 3 B per pixel
+    secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    if (rc) {
+      std::fprintf(stderr, "HIP error (pt_group): %s\n", pt_last_error());
+      return EXIT_FAILURE;
+    }
+    std::printf("%dx%d, %d spp, depth %d on %d GPU(s): %.3f s, %.2f Msamples/s\n", W, H, iters, scene->state.traceDepth, gpus,
+                secs, (double)W * H * iters / secs / 1e6);
+    if (pt_write_png_rgb8((base + ".png").c_str(), rgb8.data(), W, H) == 0) std::printf("Saved %s.png.\n", base.c_str());
+    if (pfm) {
+      scene->state.image.resize((size_t)W * H * 3);
+      if (pt_group_gather(grp, scene->state.image.data())) {
+        std::fprintf(stderr, "HIP error (pt_group_gather): %s\n", pt_last_error());
+        return EXIT_FAILURE;
+      }
+      if (pt_save_pfm((base + ".pfm").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
+        std::printf("Saved %s.pfm.\n", base.c_str());
+    }
+    pt_group_destroy(grp);
+  }
   delete scene;
   return 0;
 }

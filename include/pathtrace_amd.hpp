@@ -39,3 +39,5 @@ void pathtraceFree();
 void pathtrace(pt_uchar4* pbo, int frame, int iteration);
 // extension: flush queued iterations and refresh scene->state.image (running SUM)
 void pathtraceSyncImage();
+// extension: arithmetic mode (PT_ARITH_*, pt_amd.h) of the next pathtraceInit; default PT_ARITH_EXACT
+void pathtraceSetArith(int pt_arith);

@@ -16,7 +16,10 @@
  *     reference's raw orientation (index = x + y*W; saveImage() mirrors x later,
  *     src/main.cpp:91-97), exactly what pathtrace() leaves in
  *     scene->state.image (pathtrace.cu:648-651).
- *   - single caller thread, one global renderer instance (pathtrace.cu:446-456).
+ *   - single caller thread.  pt_init / pt_render / pt_free act on one default renderer instance, like the
+ *     reference's file-scope state (pathtrace.cu:446-456); pt_ctx_* are the same operations on explicit
+ *     instances (one per GPU), and pt_group_* drive several GPUs from one process with one RCCL gather at
+ *     image write-out.
  */
 #ifndef PT_AMD_H
 #define PT_AMD_H
@@ -88,12 +91,12 @@ typedef struct PtOptions {
   int32_t time_kernels;    /* 1: bracket every computeIntersections launch with  */
                            /*    HIP events on the render stream (pt_get_stats)  */
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
-  int32_t debug_flags;      /* profiling / A-B switches.  Results are WRONG with bits 0-3: 1 intersect skips tracing
-                               (memory-side floor of the kernel), 2 shade skips shading (every path retires),
-                               4 skip the primitive tests, 8 skip the bounce-direction sampling.  Results are
-                               UNCHANGED with bits 4-5: 16 no closer-hit cull in the subtree scans, 32 no
-                               near-first subtree order.  (Environment, tests only: PT_LDS_TABLE_KB forces the
-                               LDS staging limit of the scene tables.) */
+  int32_t debug_flags;      /* A-B switches with UNCHANGED results: 16 no closer-hit cull in the subtree scans, 32 no
+                               near-first subtree order.  Bits 0-3 are profiling ablations with WRONG results
+                               (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
+                               they exist only in -DPT_ABLATE builds of the library (tools/pmc_ablate.sh) and
+                               pt_init fails on them otherwise (pt_library_has_ablations()).  (Environment,
+                               tests only: PT_LDS_TABLE_KB forces the LDS staging limit of the scene tables.) */
   int32_t unfused_primary;  /* 1: run depth 0 as generate + intersect + shade launches instead of the fused
                                primary kernel (A/B and stage-parity runs) */
   int32_t unfused_bounces;  /* 1: depths >= 1 as separate computeIntersections + shade launches (hit records
@@ -101,8 +104,23 @@ typedef struct PtOptions {
   int32_t stripe_pixels;    /* striped tile for multi-GPU load balance: the tile consists of runs of          */
   int32_t stripe_stride;    /*   stripe_pixels pixels starting every stripe_stride pixels from pixel_begin;     */
                             /*   pixel_count counts the tile's own pixels.  0 = one contiguous run              */
-  int32_t reserved[3];
+  int32_t arith;            /* arithmetic mode of the kernels, PT_ARITH_*                                      */
+  int32_t reserved[2];
 } PtOptions;
+
+/* Arithmetic modes (PtOptions.arith).  All modes run the same algorithm with the same random draws and decisions;
+ * they differ in how float expressions are rounded.
+ *   EXACT  every operation in the reference's source order without FMA contraction, IEEE divide / sqrt, portable
+ *          sin / cos / acos: bit-identical to the CPU oracle (oracle/pt_oracle.cpp, PORTABLE mode).  The parity anchor.
+ *   FMA    the same source with FMA contraction (what nvcc does to the reference's kernels by default), IEEE
+ *          divide / sqrt kept.
+ *   FAST   FMA + hardware reciprocal / rsqrt / sqrt / sin / cos, nested-FMA matrix products, float-only
+ *          direction sampling.
+ * FMA and FAST are held to the stated tolerance against the reference semantics (tests/test_gpu_arith.py):
+ * finite; at <= 16 spp >= 99.8 % of pixels within 1e-5; PSNR >= 45 dB + 10 log10(spp / 8). */
+#define PT_ARITH_EXACT 0
+#define PT_ARITH_FMA 1
+#define PT_ARITH_FAST 2
 
 #define PT_MAX_DEPTH 64
 typedef struct PtStats {
@@ -117,6 +135,8 @@ typedef struct PtStats {
                                          computeIntersections launches cover depths >= 1 only   */
   int32_t bounces_fused;              /* 1: depths >= 1 ran in the fused bounce kernel; the timed launches
                                          (intersect_ms / intersect_launches) are then those kernels      */
+  int32_t arith;                      /* PT_ARITH_* in use                                               */
+  int32_t pad_;
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,
@@ -161,6 +181,46 @@ int pt_preview_rgba8_device(int iterations, void* rgba_dev); /* same, into a dev
 int pt_get_stats(PtStats* out);
 int pt_reset_stats(void);
 const char* pt_last_error(void);
+int pt_library_has_ablations(void); /* 1: -DPT_ABLATE build (debug_flags bits 0-3 honoured) */
+/* saveImage()'s per-pixel conversion (main.cpp:91-97 x mirror, image.cpp:26-30 clamp * 255 truncated) on the
+ * device: pixel_count*3 bytes, row-major, x mirrored inside each row; the tile must consist of whole rows.
+ * Reads back 3 B per pixel instead of 12. */
+int pt_save_u8(float samples, uint8_t* rgb8_host);
+
+/* ---- explicit renderer instances: the operations above on a context of your own (one per GPU). ---- */
+typedef struct PtContext PtContext;
+int pt_ctx_create(const PtSceneDesc* scene, const PtOptions* opt, PtContext** out); /* nothing is left behind on failure */
+int pt_ctx_destroy(PtContext* c);
+int pt_ctx_render(PtContext* c, int iter_first, int iter_count);
+int pt_ctx_sync(PtContext* c);
+int pt_ctx_readback(PtContext* c, float* rgb_sum_host);
+int pt_ctx_readback_device(PtContext* c, void* rgb_sum_dev);
+int pt_ctx_save_u8(PtContext* c, float samples, uint8_t* rgb8_host);
+int pt_ctx_save_u8_device(PtContext* c, float samples, const uint8_t** rgb8_dev); /* async on the context's stream */
+int pt_ctx_preview_rgba8(PtContext* c, int iterations, uint8_t* rgba_host);
+int pt_ctx_preview_rgba8_device(PtContext* c, int iterations, void* rgba_dev);
+int pt_ctx_get_stats(PtContext* c, PtStats* out);
+int pt_ctx_reset_stats(PtContext* c);
+const float* pt_ctx_device_image(PtContext* c); /* device pointer of the tile SUM image */
+void* pt_ctx_stream(PtContext* c);              /* the context's hipStream_t */
+int pt_ctx_pixel_count(const PtContext* c);
+int pt_ctx_device(const PtContext* c);
+
+/* ---- one process, several GPUs (BASELINE config 4).  The framebuffer is cut into row-interleaved
+ * tiles (device i of n owns rows i, i+n, ...; RNG keyed by the GLOBAL pixel index, so the assembled image is
+ * bit-identical to the single-GPU image), every device renders its tile on its own stream with no data-path
+ * collective, and the tiles meet once, at image write-out: one grouped RCCL send/recv (ncclCommInitAll
+ * communicator) into device devices[0], placed row by row there, one D2H copy.  Replaces the reference's single
+ * device (src/preview.cpp:112 cudaGLSetGLDevice(0)) and its write-out point (src/main.cpp:86-107). */
+typedef struct PtGroup PtGroup;
+int pt_group_create(const PtSceneDesc* scene, const PtOptions* base, const int* devices, int num_devices, PtGroup** out);
+int pt_group_destroy(PtGroup* g);
+int pt_group_size(const PtGroup* g);
+PtContext* pt_group_context(PtGroup* g, int i);
+int pt_group_render(PtGroup* g, int iter_first, int iter_count); /* asynchronous on every device */
+int pt_group_sync(PtGroup* g);
+int pt_group_gather(PtGroup* g, float* rgb_sum_host);             /* W*H*3 floats, raw orientation */
+int pt_group_gather_u8(PtGroup* g, float samples, uint8_t* rgb8_host); /* W*H*3 bytes as pt_save_u8, converted on each device */
 
 /* ---- stage-level entry points (same kernels, caller-supplied HOST arrays, SoA:
  * vec3 arrays are [3][n]).  Used by the parity tests; each uploads, launches the
@@ -181,6 +241,12 @@ int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, 
 /* rgb_sum: W*H*3 floats (raw orientation); writes <path> as 8-bit PNG of
  * clamp(sum/samples)*255 with the x mirror of saveImage(); no gamma. */
 int pt_save_png(const char* path, const float* rgb_sum, int w, int h, float samples);
+/* The same file from bytes that are already converted and mirrored (pt_save_u8 / pt_group_gather_u8). */
+int pt_write_png_rgb8(const char* path, const uint8_t* rgb8, int w, int h);
+/* "<name>.<UTC yyyy-mm-dd_hh-mm-ssz>.<samples>samp": the base name saveImage() composes (main.cpp:99-102,
+ * preview.cpp:18-24 currentTimeString, taken once per process like main.cpp:35; `samples` is streamed as a float like
+ * the reference's); writes at most cap bytes incl. the terminator, returns the full length. */
+int pt_output_basename(const char* name, int samples, char* out, int cap);
 int pt_save_pfm(const char* path, const float* rgb_sum, int w, int h, float samples);
 
 #ifdef __cplusplus

@@ -1,0 +1,126 @@
+"""The C++ single-process multi-GPU path (pt_group_*, csrc/pt_group.cpp; BASELINE config 4) as far as the box allows:
+with the devices that are visible (one on the test box, eight on the driver's node) the group image must equal the
+single-context image bit for bit, the on-device PNG conversion must equal the host writer's bytes, and `pt_render
+--gpus K` must produce the same files as the pathtrace.h shim path."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "cosc_4397_pathtracing_raytracing_project_amd", "pt_render")
+
+
+def visible_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+def single(scene_path, res, spp, **kw):
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    sc = capi.Scene(scene_path, res=res)
+    r = capi.Renderer(sc, **kw)
+    try:
+        r.render(1, spp)
+        return r.readback(), r.save_u8(spp)
+    finally:
+        r.free()
+
+
+def expected_u8(img_sum, w, h, spp):
+    """saveImage (main.cpp:86-107) + savePNG (image.cpp:22-39) in numpy: x mirror, clamp, * 255, truncate."""
+    avg = (img_sum.reshape(h, w, 3) / np.float32(spp))[:, ::-1]
+    return (np.minimum(np.maximum(avg, np.float32(0)), np.float32(1)) * np.float32(255)).astype(np.uint8)
+
+
+def png_pixels(path):
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(raw):
+        n = int.from_bytes(raw[pos:pos + 4], "big")
+        typ = raw[pos + 4:pos + 8]
+        if typ == b"IHDR":
+            w, h = int.from_bytes(raw[pos + 8:pos + 12], "big"), int.from_bytes(raw[pos + 12:pos + 16], "big")
+        if typ == b"IDAT":
+            idat += raw[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("arith", ["exact", "fast"])
+def test_group_of_visible_devices_equals_single_context(scene_dir, arith):
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    res, spp = (160, 101), 9  # odd row count: devices own different numbers of rows
+    ref, ref8 = single(scene_dir["cornell"], res, spp, arith=arith)
+    ndev = visible_devices()
+    for k in sorted({1, ndev}):
+        g = capi.Group(capi.Scene(scene_dir["cornell"], res=res), list(range(k)), arith=arith, iters_per_batch=4)
+        try:
+            g.render(1, 5)
+            g.render(6, 4)
+            img = g.gather()
+            u8 = g.gather_u8(spp)
+            assert g.stats(0).samples == ((res[1] + k - 1) // k) * res[0] * spp
+        finally:
+            g.free()
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{k} device(s)"
+        assert np.array_equal(u8, ref8), f"{k} device(s)"
+        assert np.array_equal(u8, expected_u8(ref, res[0], res[1], spp))
+
+
+def test_save_u8_on_device_equals_host_png_writer(scene_dir, tmp_path):
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    res, spp = (96, 64), 5
+    img, u8 = single(scene_dir["cornell"], res, spp)
+    path = str(tmp_path / "host.png")
+    capi.save_png(path, img, res[0], res[1], float(spp))
+    assert np.array_equal(png_pixels(path), u8)
+    path2 = str(tmp_path / "dev.png")
+    capi.write_png_rgb8(path2, u8)
+    assert open(path, "rb").read() == open(path2, "rb").read()
+    # tiles that are not whole rows cannot be mirrored on the device
+    sc = capi.Scene(scene_dir["cornell"], res=res)
+    r = capi.Renderer(sc, pixel_begin=10, pixel_count=200)
+    try:
+        r.render(1, 1)
+        with pytest.raises(capi.PtError, match="whole image rows"):
+            r.save_u8(1.0)
+    finally:
+        r.free()
+
+
+def test_pt_render_gpus_matches_shim_path(scene_dir, tmp_path):
+    """`pt_render --gpus 1` (pt_group + RCCL communicator + device-side PNG bytes) against the default path
+    (pathtrace.h shim + host PNG writer): identical PNG and PFM files; with every visible device too."""
+    assert os.path.exists(BIN), "pt_render not built"
+    res, spp = "160x120", "33"
+    outs = {}
+    ndev = visible_devices()
+    runs = [("shim", []), ("g1", ["--gpus", "1"])] + ([("gall", ["--gpus", "0"])] if ndev > 1 else [])
+    for tag, extra in runs:
+        out = str(tmp_path / tag)
+        p = subprocess.run([BIN, scene_dir["cornell"], "--res", res, "--spp", spp, "--out", out, "--pfm"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr + p.stdout
+        assert "Msamples/s" in p.stdout
+        outs[tag] = (open(f"{out}.{spp}samp.png", "rb").read(), open(f"{out}.{spp}samp.pfm", "rb").read())
+    for tag in outs:
+        assert outs[tag] == outs["shim"], tag
+    p = subprocess.run([BIN, scene_dir["cornell"], "--gpus", str(ndev + 1)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "visible" in p.stderr
+
+
+def test_pt_render_stamp_uses_reference_file_name(scene_dir, tmp_path):
+    import re
+    p = subprocess.run([BIN, scene_dir["cornell"], "--res", "32x32", "--spp", "2", "--stamp", "--arith", "fma"],
+                       capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr
+    names = os.listdir(tmp_path)
+    # <FILE>.<UTC start time>.<samples>samp.png (main.cpp:99-102, preview.cpp:18-24)
+    assert any(re.fullmatch(r"cornell\.\d{4}-\d\d-\d\d_\d\d-\d\d-\d\dz\.2samp\.png", n) for n in names), names
