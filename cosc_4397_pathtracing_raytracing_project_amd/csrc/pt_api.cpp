@@ -338,7 +338,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
       k.bounce(g.stream, g.grid_bounce, sc, b, d, queues_for(g, g.grid_bounce), cin, cout, g.buf[d & 1], g.buf[(d + 1) & 1],
                g.d_final);
     } else {
-      k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy);
+      k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy, d == 0);
     }
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
@@ -837,7 +837,7 @@ int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, f
     HIP_OK(hipMemcpy(pb.d + c * cap, dir + (size_t)c * n, (size_t)n * 4, hipMemcpyHostToDevice));
   }
   HIP_OK(hipMemcpy(cnt, &n, 4, hipMemcpyHostToDevice));
-  g.k->intersect(g.stream, g.grid, tables(g), qs, cnt, pb, hb, g.legacy);
+  g.k->intersect(g.stream, g.grid, tables(g), qs, cnt, pb, hb, g.legacy, false);
   HIP_OK(hipStreamSynchronize(g.stream));
   HIP_OK(hipMemcpy(t, hb.t, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_OK(hipMemcpy(material, hb.mat, (size_t)n * 4, hipMemcpyDeviceToHost));

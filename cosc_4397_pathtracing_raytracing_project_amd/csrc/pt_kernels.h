@@ -80,9 +80,10 @@ struct KernelApi {
   // Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.
   void (*bounce)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                  const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba);
-  // computeIntersections over the live paths of every queue.
+  // computeIntersections over the live paths of every queue.  exact_arith: these are primary rays (depth 0), which
+  // are traced with the reference's exact arithmetic in every mode (pt_kernels.hip, namespace ex).
   void (*intersect)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
-                    ptd::PathBuf paths, ptd::HitBuf hits, bool legacy);
+                    ptd::PathBuf paths, ptd::HitBuf hits, bool legacy, bool exact_arith);
   // shadeAndExtendRays + compaction + retirement.
   void (*shade)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                 const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,

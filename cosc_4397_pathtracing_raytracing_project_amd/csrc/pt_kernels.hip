@@ -57,6 +57,34 @@ namespace {
 #define PT_DEV __device__ __forceinline__
 
 constexpr bool kFast = PT_ARITH == 2;
+// Components of the fast mode, individually switchable (-DPT_FAST_x=0) for the flip-rate bisection of
+// tools/arith_bisect.sh; the product builds leave all of them on.
+#ifndef PT_FAST_TRIG
+#define PT_FAST_TRIG 1  // direction sampling: v_sin / v_cos in revolutions, sqrt form of the diffuse lobe, no doubles
+#endif
+#ifndef PT_FAST_DIV
+#define PT_FAST_DIV 1   // v_rcp_f32 instead of IEEE divides
+#endif
+#ifndef PT_FAST_SQRT
+#define PT_FAST_SQRT 1  // v_rsq_f32 / v_sqrt_f32 instead of IEEE sqrt (+ divide) in normalize / length
+#endif
+#ifndef PT_FAST_SLAB
+#define PT_FAST_SLAB 1  // AABB test as (b * inv - o * inv) FMAs with min/max per axis
+#endif
+#ifndef PT_FAST_MV
+#define PT_FAST_MV 1    // nested-FMA matrix-vector products and dot products
+#endif
+#ifndef PT_FAST_QO
+#define PT_FAST_QO 0    // 1: ray origin -> object space as a nested-FMA product too.  Off in the product: this is the one
+                        // ill-conditioned product of the primitive test (thin wall: 100 * z + 500), and rounding it like the
+                        // reference does (unfused, GLM order) removes 90 % of the remaining fma / fast sample flips
+                        // (cornell 256^2 x 16 spp: 25 -> 3 pixels for fma, 46 -> 3 for fast; tools/arith_flips.py)
+#endif
+#ifndef PT_FAST_RENORM
+#define PT_FAST_RENORM 1  // getPointOnRay does not normalise the already normalised object-space direction again
+#endif
+constexpr bool kFastTrig = kFast && PT_FAST_TRIG, kFastDiv = kFast && PT_FAST_DIV, kFastSqrt = kFast && PT_FAST_SQRT,
+               kFastSlab = kFast && PT_FAST_SLAB, kFastMV = kFast && PT_FAST_MV, kFastRenorm = kFast && PT_FAST_RENORM, kFastQO = PT_ARITH == 0 || (kFast && PT_FAST_QO);
 // Ablation switches of tools/pmc_ablate.sh (BatchInfo::debug, wrong results) exist only in -DPT_ABLATE builds.
 #ifdef PT_ABLATE
 constexpr bool kAblate = true;
@@ -74,53 +102,6 @@ struct f3 {
   float x, y, z;
 };
 PT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
-PT_DEV f3 add(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
-PT_DEV f3 sub(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
-PT_DEV f3 mul(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
-PT_DEV f3 scl(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-PT_DEV f3 neg(f3 a) { return mk(-a.x, -a.y, -a.z); }
-// Scalar primitives of the arithmetic modes.  exact / fma: IEEE divide and square root (the compiler's correctly
-// rounded expansions); fast: the hardware approximations v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp).
-PT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-PT_DEV float rcp_(float x) { return kFast ? __builtin_amdgcn_rcpf(x) : 1.0f / x; }
-PT_DEV float div_(float a, float b) { return kFast ? a * __builtin_amdgcn_rcpf(b) : a / b; }
-PT_DEV float sqrt_(float x) { return kFast ? __builtin_amdgcn_sqrtf(x) : __builtin_sqrtf(x); }
-PT_DEV float dot(f3 a, f3 b) {
-  if (kFast) return fma_(a.x, b.x, fma_(a.y, b.y, a.z * b.z));
-  return (a.x * b.x + a.y * b.y) + a.z * b.z;
-}
-PT_DEV f3 cross(f3 x, f3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
-PT_DEV f3 normalize(f3 v) { return scl(v, kFast ? __builtin_amdgcn_rsqf(dot(v, v)) : 1.0f / __builtin_sqrtf(dot(v, v))); }
-PT_DEV float length(f3 v) { return sqrt_(dot(v, v)); }
-PT_DEV f3 madd(f3 a, float s, f3 b) {  // a * s + b
-  if (kFast) return mk(fma_(a.x, s, b.x), fma_(a.y, s, b.y), fma_(a.z, s, b.z));
-  return add(scl(a, s), b);
-}
-
-// vec3(m * vec4(v, w)) in GLM order: (m0*v0 + m1*v1) + (m2*v2 + m3*w); m is [c*3+r].  W is 0 (direction) or 1
-// (point); fast: one multiply + FMA chain per row.
-template <int W>
-PT_DEV f3 mulMV(const float* m, f3 v) {
-  f3 r;
-  if (kFast) {
-    r.x = fma_(m[0], v.x, fma_(m[3], v.y, W ? fma_(m[6], v.z, m[9]) : m[6] * v.z));
-    r.y = fma_(m[1], v.x, fma_(m[4], v.y, W ? fma_(m[7], v.z, m[10]) : m[7] * v.z));
-    r.z = fma_(m[2], v.x, fma_(m[5], v.y, W ? fma_(m[8], v.z, m[11]) : m[8] * v.z));
-    return r;
-  }
-  const float w = (float)W;
-  r.x = (m[0] * v.x + m[3] * v.y) + (m[6] * v.z + m[9] * w);
-  r.y = (m[1] * v.x + m[4] * v.y) + (m[7] * v.z + m[10] * w);
-  r.z = (m[2] * v.x + m[5] * v.y) + (m[8] * v.z + m[11] * w);
-  return r;
-}
-
-PT_DEV int lane_id() { return (int)(threadIdx.x & 63); }
-// value of v in lane src_lane
-PT_DEV float bperm(int src_lane, float v) {
-  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
-
 // Exact a / n and a % n for 0 <= a < 2^30 and quotients below 2^15 (sample ids / tile pixels,
 // pixel index / image width): float estimate + one correction step either way, ~10 VALU instead of
 // the ~35 of a 32-bit integer division.  inv_n = 1.0f / n computed once per kernel.
@@ -136,6 +117,73 @@ PT_DEV void divmod(int a, int n, float inv_n, int& q, int& r) {
   }
   q = k;
   r = rem;
+}
+
+// intersectAABB's per-ray constants (see ray_inv in pt_arith.inc)
+struct RayInv {
+  float ix, iy, iz;
+  bool sx, sy, sz;
+  float nx, ny, nz;  // fast mode: -origin * reciprocal, so that (b - o) / d is one FMA per plane
+};
+
+}  // namespace
+
+// The arithmetic, twice (see pt_arith.inc).  Primary rays are identical in every iteration of a pixel, so a rounding
+// difference that flips one of their decisions — the image diagonals of the square cornell frame look exactly along
+// the box's corner edges, where two walls tie to the last bit of t — would repeat in every sample of that pixel instead
+// of averaging out; measured: 90 % of all fma-vs-reference sample flips at 256 x 256 are such depth-0 ties.  Depth 0
+// therefore runs the reference's exact primitive tests (namespace ex) in every arithmetic mode; the stochastic
+// bounces use the mode's arithmetic (namespace md).
+#pragma clang fp contract(off)
+namespace ex {
+namespace {
+constexpr bool kFastDiv = false, kFastSqrt = false, kFastMV = false, kFastRenorm = false, kFastSlab = false, kFastQO = true;
+#include "pt_arith.inc"
+}  // namespace
+}  // namespace ex
+#if PT_ARITH != 0
+#pragma clang fp contract(fast)
+#endif
+namespace md {
+namespace {
+constexpr bool kFastDiv = PT_NS::kFastDiv, kFastSqrt = PT_NS::kFastSqrt, kFastMV = PT_NS::kFastMV, kFastRenorm = PT_NS::kFastRenorm,
+               kFastSlab = PT_NS::kFastSlab, kFastQO = PT_NS::kFastQO;
+#include "pt_arith.inc"
+}  // namespace
+}  // namespace md
+namespace {
+using namespace md;
+// Arithmetic flavour of a call site: Ar<true> = the reference's exact arithmetic (namespace ex), Ar<false> = the
+// build's mode.  kD0 selects the flavour of everything geometric at depth 0; in the exact build both are the same
+// arithmetic, so it stays on md and nothing is instantiated twice.
+constexpr bool kD0 = PT_ARITH != 0;
+template <bool EX>
+struct Ar {
+  static PT_DEV RayInv ray_inv(f3 d, f3 o) { if constexpr (EX) return ex::ray_inv(d, o); else return md::ray_inv(d, o); }
+  static PT_DEV bool slab(f3 o, const RayInv& ri, float a, float b, float c, float d, float e, float f) {
+    if constexpr (EX) return ex::slab(o, ri, a, b, c, d, e, f); else return md::slab(o, ri, a, b, c, d, e, f);
+  }
+  static PT_DEV bool slab_rel(const RayInv& ri, float a, float b, float c, float d, float e, float f) {
+    if constexpr (EX) return ex::slab_rel(ri, a, b, c, d, e, f); else return md::slab_rel(ri, a, b, c, d, e, f);
+  }
+  static PT_DEV bool slab_t(f3 o, const RayInv& ri, float a, float b, float c, float d, float e, float f, float& tn) {
+    if constexpr (EX) return ex::slab_t(o, ri, a, b, c, d, e, f, tn); else return md::slab_t(o, ri, a, b, c, d, e, f, tn);
+  }
+  template <int TYPE, bool QO>
+  static PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro, f3 rd, f3& point, f3& normal, f3 qo_pre) {
+    if constexpr (EX) return ex::geom_test<TYPE, QO>(G, ro, rd, point, normal, qo_pre);
+    else return md::geom_test<TYPE, QO>(G, ro, rd, point, normal, qo_pre);
+  }
+  static PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p) {
+    if constexpr (EX) return ex::camera_dir(cam, inv_w, p); else return md::camera_dir(cam, inv_w, p);
+  }
+  static PT_DEV f3 xf_point(const float* m, f3 v) { if constexpr (EX) return ex::mulMV<1>(m, v); else return md::mulMV<1>(m, v); }
+};
+
+PT_DEV int lane_id() { return (int)(threadIdx.x & 63); }
+// value of v in lane src_lane
+PT_DEV float bperm(int src_lane, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 
 // ───────────────────────────── RNG ──────────────────────────────────────────
@@ -196,19 +244,6 @@ PT_DEV int global_pixel(const BatchInfo& b, int p) {
 }
 
 // ───────────────────────────── generate ────────────────────────────────────
-// generateRayFromCamera (pathtrace.cu:270-286) for global pixel index p:
-// dir = normalize(view - right*pl.x*(x - W/2) - up*pl.y*(y - H/2)); no jitter, `iter` unused.
-PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p) {
-  int x, y;
-  divmod(p, cam.res_x, inv_w, y, x);
-  const float fx = (float)x - cam.res_x * 0.5f;
-  const float fy = (float)y - cam.res_y * 0.5f;
-  const f3 view = mk(cam.view[0], cam.view[1], cam.view[2]);
-  const f3 a = scl(scl(mk(cam.right[0], cam.right[1], cam.right[2]), cam.pl_x), fx);
-  const f3 c = scl(scl(mk(cam.up[0], cam.up[1], cam.up[2]), cam.pl_y), fy);
-  return normalize(sub(sub(view, a), c));
-}
-
 __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo b, ptd::Queues qs, ptd::PathBuf out,
                                                      int32_t* __restrict__ cnt0) {
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -233,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
       int k, pl;
       divmod((int)gid, b.N, inv_n, k, pl);
       const int p = global_pixel(b, pl);  // global pixel index
-      const f3 d = camera_dir(cam, inv_w, p);
+      const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p);
       const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
       out.o[at] = cam.pos[0], out.o[S + at] = cam.pos[1], out.o[2 * S + at] = cam.pos[2];
       out.d[at] = d.x, out.d[S + at] = d.y, out.d[2 * S + at] = d.z;
@@ -250,155 +285,6 @@ struct HitRec {
   f3 p;
   int geom;
 };
-
-// Primitive tests.  The object-space transform of the ray and the world-space reconstruction of
-// point / normal / distance are common to both types; only the middle (slab vs quadratic) differs.
-// TYPE: 1 cube (boxIntersectionTest, intersections.h:48-90), 0 sphere (sphereIntersectionTest,
-// intersections.h:102-144), -1 decided per lane from G->type.  Returns t (-1 = no hit).
-// QO: the object-space origin is supplied by the caller (primary rays share the camera position, so it is one
-// value per geom: computed once per block by the primary kernel with this same mulMV).
-template <int TYPE, bool QO = false>
-PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro_w, f3 rd_w, f3& point, f3& normal, f3 qo_pre = f3{0.f, 0.f, 0.f}) {
-  const f3 qo = QO ? qo_pre : mulMV<1>(G->inv, ro_w);
-  const f3 qd = normalize(mulMV<0>(G->inv, rd_w));
-  const bool is_box = TYPE < 0 ? (G->type == 1) : (TYPE == 1);
-  float t;
-  f3 nobj = mk(0.f, 0.f, 0.f);
-  bool flip = false;
-  int ncode = 0;  // cube: which of the 7 possible object-space normals (0 = zero vector, 1 + 2*axis + (sign > 0))
-  if (is_box) {
-    float tmin = -1e38f, tmax = 1e38f;
-    int tmin_c = 0, tmax_c = 0;
-    const float qdv[3] = {qd.x, qd.y, qd.z};
-    const float qov[3] = {qo.x, qo.y, qo.z};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      float t1, t2;
-      if (kFast) {  // one reciprocal per axis; the subtract-then-multiply form keeps 0-direction axes at +-inf
-        const float r = __builtin_amdgcn_rcpf(qdv[a]);
-        t1 = (-0.5f - qov[a]) * r;
-        t2 = (+0.5f - qov[a]) * r;
-      } else {
-        t1 = (-0.5f - qov[a]) / qdv[a];
-        t2 = (+0.5f - qov[a]) / qdv[a];
-      }
-      const float ta = t1 < t2 ? t1 : t2;  // glm::min
-      const float tb = t1 > t2 ? t1 : t2;  // glm::max
-      const int c = 1 + 2 * a + (t2 < t1 ? 1 : 0);  // n[xyz] = t2 < t1 ? +1 : -1
-      if (ta > 0.f && ta > tmin) {
-        tmin = ta;
-        tmin_c = c;
-      }
-      if (tb < tmax) {
-        tmax = tb;
-        tmax_c = c;
-      }
-    }
-    if (!(tmax >= tmin && tmax > 0.f)) return -1.0f;
-    if (tmin <= 0.f) {
-      tmin = tmax;
-      tmin_c = tmax_c;
-    }
-    t = tmin;
-    ncode = tmin_c;
-  } else {
-    // radius .5 → powf(.5, 2) = .25
-    const float along = dot(qo, qd);
-    const float disc = kFast ? fma_(along, along, 0.25f - dot(qo, qo)) : along * along - (dot(qo, qo) - 0.25f);
-    if (disc < 0.f) return -1.0f;
-    const float root = sqrt_(disc);
-    const float t1 = -along + root;
-    const float t2 = -along - root;
-    if (t1 < 0.f && t2 < 0.f) return -1.0f;
-    if (t1 > 0.f && t2 > 0.f) {
-      t = t2 < t1 ? t2 : t1;  // min(t1, t2)
-    } else {
-      t = t1 < t2 ? t2 : t1;  // max(t1, t2)
-      flip = true;            // !outside → normal negated
-    }
-  }
-  // getPointOnRay (intersections.h:27-29): origin + (t - .0001f) * normalize(direction); qd is already a unit
-  // vector, so the fast mode does not normalise it a second time
-  const f3 objp = kFast ? madd(qd, t - .0001f, qo) : add(qo, scl(normalize(qd), t - .0001f));
-  if (!is_box) nobj = objp;
-  point = mulMV<1>(G->xf, objp);
-  if (is_box) {
-    normal = mk(G->box_normal[ncode][0], G->box_normal[ncode][1], G->box_normal[ncode][2]);  // precomputed, exact
-  } else {
-    normal = normalize(mulMV<0>(G->invT, nobj));
-    if (flip) normal = neg(normal);
-  }
-  return length(sub(ro_w, point));
-}
-
-// intersectAABB (pathtrace.cu:113-128) with the reciprocal direction hoisted (the reference
-// recomputes 1/dir per node, same value) and the swap expressed as a select on its sign.
-// The reference returns false at the first axis with tmax <= tmin; tmin only grows and tmax only
-// shrinks, so one test after the third axis is equivalent.
-struct RayInv {
-  float ix, iy, iz;
-  bool sx, sy, sz;
-  float nx, ny, nz;  // fast mode: -origin * reciprocal, so that (b - o) / d is one FMA per plane
-};
-// Reciprocal direction of a ray starting at o.  fast: |d| is clamped to >= 1e-20 so that the reciprocal stays finite
-// (an axis-parallel ray would otherwise produce inf - inf in the FMA form of the slab test).
-PT_DEV RayInv ray_inv(f3 d, f3 o) {
-  RayInv r;
-  if (kFast) {
-    const float dx = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), 1e-20f), d.x);
-    const float dy = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), 1e-20f), d.y);
-    const float dz = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), 1e-20f), d.z);
-    r.ix = __builtin_amdgcn_rcpf(dx), r.iy = __builtin_amdgcn_rcpf(dy), r.iz = __builtin_amdgcn_rcpf(dz);
-  } else {
-    r.ix = 1.0f / d.x, r.iy = 1.0f / d.y, r.iz = 1.0f / d.z;
-  }
-  r.sx = r.ix < 0.0f, r.sy = r.iy < 0.0f, r.sz = r.iz < 0.0f;
-  r.nx = -o.x * r.ix, r.ny = -o.y * r.iy, r.nz = -o.z * r.iz;
-  return r;
-}
-// Slab test from the six plane distances (near/far per axis by min/max): the fast-mode form.
-PT_DEV bool slab_planes(float ax, float bx, float ay, float by, float az, float bz, float& tn) {
-  const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-  const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-  tn = __builtin_fmaxf(t0, 0.0f);
-  return !(t1 <= tn);
-}
-// slab() that also returns the entry distance (for the closer-hit cull of the subtree scans).
-PT_DEV bool slab_t(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz, float& tn) {
-  if (kFast)
-    return slab_planes(fma_(lox, ri.ix, ri.nx), fma_(hix, ri.ix, ri.nx), fma_(loy, ri.iy, ri.ny), fma_(hiy, ri.iy, ri.ny),
-                       fma_(loz, ri.iz, ri.nz), fma_(hiz, ri.iz, ri.nz), tn);
-  const float t0x = ((ri.sx ? hix : lox) - o.x) * ri.ix;
-  const float t1x = ((ri.sx ? lox : hix) - o.x) * ri.ix;
-  const float t0y = ((ri.sy ? hiy : loy) - o.y) * ri.iy;
-  const float t1y = ((ri.sy ? loy : hiy) - o.y) * ri.iy;
-  const float t0z = ((ri.sz ? hiz : loz) - o.z) * ri.iz;
-  const float t1z = ((ri.sz ? loz : hiz) - o.z) * ri.iz;
-  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
-  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
-  tn = tmin;
-  return !(tmax <= tmin);
-}
-PT_DEV bool slab(f3 o, const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
-  float tn;
-  return slab_t(o, ri, lox, loy, loz, hix, hiy, hiz, tn);
-}
-// slab() on a box given relative to the ray origin (lo - o, hi - o precomputed with the same subtraction).
-PT_DEV bool slab_rel(const RayInv& ri, float lox, float loy, float loz, float hix, float hiy, float hiz) {
-  if (kFast) {
-    float tn;
-    return slab_planes(lox * ri.ix, hix * ri.ix, loy * ri.iy, hiy * ri.iy, loz * ri.iz, hiz * ri.iz, tn);
-  }
-  const float t0x = (ri.sx ? hix : lox) * ri.ix;
-  const float t1x = (ri.sx ? lox : hix) * ri.ix;
-  const float t0y = (ri.sy ? hiy : loy) * ri.iy;
-  const float t1y = (ri.sy ? loy : hiy) * ri.iy;
-  const float t0z = (ri.sz ? hiz : loz) * ri.iz;
-  const float t1z = (ri.sz ? loz : hiz) * ri.iz;
-  const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(0.0f, t0x), t0y), t0z);
-  const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fminf(FLT_MAX, t1x), t1y), t1z);
-  return !(tmax <= tmin);
-}
 
 // Near-first order of a ray's entered subtrees.  When the top list is a complete level of a balanced tree its
 // entries are laid out by path code (bit 4 = child taken at the root, ... bit 0 = at level 4; pt_api.cpp build_top),
@@ -423,13 +309,14 @@ PT_DEV uint32_t octant_mask(const RayInv& ri, unsigned long long top_xor) {
 // One step of a lane's stackless subtree scan.  On return `cur` is advanced, `cand` says whether the node is a
 // leaf whose box the ray passes (and that is not culled), `leaf` is its index in `nodes`, `geom` its geom index.
 // bt: the ray's best hit distance so far + SceneTables::cull_margin (closer-hit cull).
+template <bool EX = false>
 PT_DEV void scan_step(const ptd::Node* __restrict__ nodes, f3 o, const RayInv& ri, bool act, int& cur, float bt,
                       bool& cand, int& leaf, int& geom) {
   const int at_n = act ? cur : 0;
   const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
   const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
   float tn;
-  const bool in = act && slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
+  const bool in = act && Ar<EX>::slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
   geom = __float_as_int(NB.w);
   cand = in && geom >= 0;
   leaf = at_n;
@@ -480,20 +367,21 @@ PT_DEV void steal_step(Walker& w, uint32_t& pend, uint32_t xm, bool idle, unsign
 }
 // Legacy traversal (kept for A/B measurements, PtOptions flag): one lane walks the threaded
 // tree and runs each primitive test as soon as the wave reaches it.
+template <bool EX>
 PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const ptd::Geom* __restrict__ geoms, f3 o, f3 d) {
   HitRec h;
   h.t = FLT_MAX;
   h.geom = -1;
   h.n = mk(0.f, 0.f, 0.f);
   h.p = mk(0.f, 0.f, 0.f);
-  const RayInv ri = ray_inv(d, o);
+  const RayInv ri = Ar<EX>::ray_inv(d, o);
   int i = 0;
   while (true) {
     int g = -1;
     while (i < num_nodes) {
       const float4 A = reinterpret_cast<const float4*>(nodes)[2 * i];      // bmin.xyz, bmax.x
       const float4 B = reinterpret_cast<const float4*>(nodes)[2 * i + 1];  // bmax.yz, skip, geom
-      if (!slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y)) {
+      if (!Ar<EX>::slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y)) {
         i = __float_as_int(B.z);
         continue;
       }
@@ -506,7 +394,7 @@ PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const pt
     }
     if (g < 0) break;
     f3 pt, nrm;
-    const float t = geom_test<-1>(geoms + g, o, d, pt, nrm);
+    const float t = Ar<EX>::template geom_test<-1, false>(geoms + g, o, d, pt, nrm, mk(0.f, 0.f, 0.f));
     if (t > 0.f && t < h.t) {  // strict <: first found wins ties (pathtrace.cu:314)
       h.t = t;
       h.geom = g;
@@ -517,7 +405,7 @@ PT_DEV HitRec trace(const ptd::Node* __restrict__ nodes, int num_nodes, const pt
   return h;
 }
 
-template <bool TABLES_IN_LDS>
+template <bool TABLES_IN_LDS, bool EX>
 __global__ __launch_bounds__(kBlock) void k_intersect_legacy(SceneTables sc, ptd::Queues qs,
                                                              const int32_t* __restrict__ cnt_in, ptd::PathBuf paths,
                                                              ptd::HitBuf hits) {
@@ -543,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_legacy(SceneTables sc, ptd
       const int64_t at = (int64_t)q * qs.cap + i;
       const f3 o = mk(paths.o[at], paths.o[S + at], paths.o[2 * S + at]);
       const f3 d = mk(paths.d[at], paths.d[S + at], paths.d[2 * S + at]);
-      const HitRec h = trace(nodes, sc.num_nodes, geoms, o, d);
+      const HitRec h = trace<EX>(nodes, sc.num_nodes, geoms, o, d);
       const bool hit = h.geom >= 0;
       // record layout of the reference after its per-depth memset (pathtrace.cu:562):
       // miss → t = -1 and zeros elsewhere.
@@ -585,7 +473,7 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 // lanes and only the slab / quadratic middle parts diverge (geom_test<-1>).
 // CAM (primary kernel): every ray starts at the camera, so the origin needs no fetch; QO (tables in LDS): its
 // object-space image comes from the per-geom table qo_tab.
-template <int TYPE, bool CAM, bool QO>
+template <int TYPE, bool CAM, bool QO, bool EX>
 PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph, int lane, f3 o, f3 d,
                       const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab) {
   const bool valid = lane < nc + nsph;
@@ -598,8 +486,8 @@ PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph
   const ptd::Geom* G = geoms + gi;
   f3 pt, nrm;
   float t;
-  if (QO) t = geom_test<TYPE, true>(G, ro, rd, pt, nrm, mk(qo_tab[3 * gi], qo_tab[3 * gi + 1], qo_tab[3 * gi + 2]));
-  else t = geom_test<TYPE>(G, ro, rd, pt, nrm);
+  if (QO) t = Ar<EX>::template geom_test<TYPE, true>(G, ro, rd, pt, nrm, mk(qo_tab[3 * gi], qo_tab[3 * gi + 1], qo_tab[3 * gi + 2]));
+  else t = Ar<EX>::template geom_test<TYPE, false>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f));
   const uint32_t tb = __float_as_uint(t);
   if (valid && t > 0.f && tb < 0x7f7fffffu) {
     const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
@@ -614,30 +502,30 @@ PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph
 // Chunk plan (a typical group at depth >= 1 holds ~55 cubes and ~12 spheres): full chunks of cubes,
 // then the remaining cubes together with the spheres in ONE mixed chunk if they fit in 64 lanes
 // (costs ~1.3x a pure chunk instead of two pure chunks), otherwise separately.
-template <bool CAM, bool QO>
+template <bool CAM, bool QO, bool EX>
 PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
                              const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab) {
   const int sbase = kCandCap - ns;
   int c0 = 0;
-  for (; c0 + 64 <= nb; c0 += 64) run_chunk<1, CAM, QO>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms, qo_tab);
+  for (; c0 + 64 <= nb; c0 += 64) run_chunk<1, CAM, QO, EX>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms, qo_tab);
   const int rem = nb - c0;
   if (rem > 0 && ns > 0 && rem + ns <= 64) {
-    run_chunk<-1, CAM, QO>(w, c0, rem, sbase, ns, lane, o, d, nodes, geoms, qo_tab);
+    run_chunk<-1, CAM, QO, EX>(w, c0, rem, sbase, ns, lane, o, d, nodes, geoms, qo_tab);
     return;
   }
-  if (rem > 0) run_chunk<1, CAM, QO>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms, qo_tab);
-  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0, CAM, QO>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
+  if (rem > 0) run_chunk<1, CAM, QO, EX>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms, qo_tab);
+  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0, CAM, QO, EX>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
 }
 
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
 // w.best[lane] holds the lane's (t bits << 32 | leaf) key (kNoHit if none) and w.rec its normal/point.
 // CAM: primary rays — `top` holds the entries' boxes relative to the camera position (slab_rel) and qo_tab the
 // camera position in every geom's object space (run_chunk<.., true>).
-template <bool CAM, bool QO = CAM>
+template <bool CAM, bool QO, bool EX>
 PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull,
                         unsigned long long top_xor, const float* qo_tab = nullptr) {
-  const RayInv ri = ray_inv(d, o);
+  const RayInv ri = Ar<EX>::ray_inv(d, o);
   w.best[lane] = kNoHit;
   int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
   uint32_t pend = 0;   // per lane: top entries that are subtrees and whose box this ray passes
@@ -649,12 +537,12 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
     if (e + 1 < ntop) A = top[2 * e + 2], B = top[2 * e + 3];
     const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
-    const bool pass = valid && (CAM ? slab_rel(ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y) : slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y));
+    const bool pass = valid && (CAM ? Ar<EX>::slab_rel(ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y) : Ar<EX>::slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y));
     if (t_link < 0) {  // leaf entry: type is wave-uniform
       const unsigned long long m = __ballot(pass);
       if (m) {
         if (nb + ns + 64 > kCandCap) {
-          flush_candidates<CAM, QO>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+          flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
           nb = ns = 0;
         }
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -699,13 +587,13 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * wk.own + 1]) + cull;
       bool cand;
       int at_n, aux;
-      scan_step(nodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
+      scan_step<EX>(nodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
       const bool cbox = cand && geoms[aux].type == 1;
       const bool csph = cand && !cbox;
       const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
       if (mb | msp) {
         if (nb + ns + 128 > kCandCap) {
-          flush_candidates<CAM, QO>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+          flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
           nb = ns = 0;
         }
         const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)wk.own;
@@ -719,10 +607,10 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       }
     }
   }
-  if (nb + ns) flush_candidates<CAM, QO>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+  if (nb + ns) flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
 }
 
-template <bool TABLES_IN_LDS>
+template <bool TABLES_IN_LDS, bool EX>
 __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queues qs, const int32_t* __restrict__ cnt_in,
                                                       ptd::PathBuf paths, ptd::HitBuf hits) {
   extern __shared__ float4 lds_raw[];
@@ -782,7 +670,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
       no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
       nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
     }
-    trace_group<false>(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
+    trace_group<false, false, EX>(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
 
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -853,7 +741,7 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
   if (depth > 3) {  // Russian roulette
     const float q = __builtin_fmaxf(mcolor.x, __builtin_fmaxf(mcolor.y, mcolor.z));
     if (rng.u01() > q) return bo;
-    if (kFast) s.c = scl(s.c, __builtin_amdgcn_rcpf(q));
+    if (kFastDiv) s.c = scl(s.c, __builtin_amdgcn_rcpf(q));
     else s.c = mk(s.c.x / q, s.c.y / q, s.c.z / q);
   }
   const float reflectivity = m->reflective;
@@ -899,7 +787,7 @@ PT_DEV void shade_bounce_fast(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
   s.d = perturb ? pert : refl;
 }
 PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
-  if (kFast) return shade_bounce_fast(bo, hn, hp, s);
+  if (kFastTrig) return shade_bounce_fast(bo, hn, hp, s);
   // The specular branch (pathtrace.cu:402-422) and the diffuse branch (:424-435, :225-238) have the
   // same shape — a frame around an axis f, three trigonometric evaluations, normalize(t*x + f*y + b*z)
   // — so both are evaluated by ONE instruction stream with per-lane operands instead of two divergent
@@ -973,6 +861,21 @@ PT_DEV void emit_survivors(const Reservation& r, bool alive, const ShadeIO& s, i
       out.slot[to] = slot;
     }
   }
+}
+
+// Deferred emission (fused kernels).  The reservation is a RETURNING global atomic: ~2-3 thousand cycles round trip,
+// far more than the direction sampling it used to hide behind (fast mode: ~70 instructions).  The survivors of a
+// shaded group therefore wait in registers until the NEXT group's candidate search has run, and are stored then.
+struct Deferred {
+  Reservation res;
+  ShadeIO s;
+  int slot;
+  bool alive;
+  bool any;  // wave-uniform: survivors pending
+};
+PT_DEV void flush_deferred(Deferred& df, int64_t qbase, ptd::PathBuf out) {
+  if (df.any) emit_survivors(df.res, df.alive, df.s, df.slot, qbase, out);
+  df.any = false;
 }
 
 __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
@@ -1132,6 +1035,41 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
     ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
     ray[3 * 64] = d.x, ray[4 * 64] = d.y, ray[5 * 64] = d.z;
   }
+  if (!SUB) {
+    // Every top entry is a leaf (the LDS-table kernels): first all box tests — one bit per entry in a per-lane mask, boxes
+    // fetched one entry ahead into alternating registers (unrolled by two, no copies) — then the appends lane-major: in
+    // round j every lane that still has candidates files one, so the ballot / rank / ring arithmetic runs once per round
+    // (max candidates of a lane, ~3) instead of once per entry (7 for cornell.txt).  The order of the ring entries changes,
+    // the set does not, and the closest-hit key is order-independent.
+    uint32_t mask = 0;
+    float4 A0 = top[0], B0 = top[1];
+    int e = 0;
+    for (; e + 1 < ntop; e += 2) {
+      const float4 A1 = top[2 * e + 2], B1 = top[2 * e + 3];
+      mask |= slab(o, ri, A0.x, A0.y, A0.z, A0.w, B0.x, B0.y) ? (1u << e) : 0u;
+      if (e + 2 < ntop) A0 = top[2 * e + 4], B0 = top[2 * e + 5];
+      mask |= slab(o, ri, A1.x, A1.y, A1.z, A1.w, B1.x, B1.y) ? (2u << e) : 0u;
+    }
+    if (e < ntop) mask |= slab(o, ri, A0.x, A0.y, A0.z, A0.w, B0.x, B0.y) ? (1u << e) : 0u;
+    mask = valid ? mask : 0u;
+    const uint32_t tag = ((uint32_t)par << 6) | (uint32_t)lane;
+    while (true) {
+      const unsigned long long m = __ballot(mask != 0u);
+      if (!m) break;
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+      if (mask != 0u) {
+        const int te = __builtin_ctz(mask);
+        mask &= mask - 1u;
+        const uint32_t leaf = __float_as_uint(reinterpret_cast<const float*>(top)[8 * te + 6]);  // TopEntry::idx
+        c.ent[(c.head + c.count + rank) & (kRing - 1)] = (leaf << 7) | tag;
+      }
+      const int cnt = __popcll(m);
+      c.count += cnt;
+      c.appended += cnt;
+      if (c.count >= 64) carry_chunk(c, 64, lane, nodes, geoms);
+    }
+    return;
+  }
   uint32_t pend = 0;  // per lane: top entries that are subtrees and whose box this ray passes
   float4 A = top[0], B = top[1];
   for (int e = 0; e < ntop; ++e) {
@@ -1189,7 +1127,7 @@ struct Pending {
 PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
                           const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
                           int depth, float inv_n, float4* __restrict__ final_rgba,
-                          int32_t* __restrict__ counter, int64_t qbase, ptd::PathBuf out, int lane) {
+                          int32_t* __restrict__ counter, Deferred& df, int lane) {
   const unsigned long long best = cy.best[pg.par * 64 + lane];
   const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
   ShadeIO s;
@@ -1214,10 +1152,13 @@ PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __
     divmod(pg.slot, b.N, inv_n, k, p);
     bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, b, depth, k), global_pixel(b, p), ht, hmat, s);
   }
-  const Reservation res = retire_and_reserve(pg.valid, s, pg.slot, final_rgba, counter, lane);
+  df.res = retire_and_reserve(pg.valid, s, pg.slot, final_rgba, counter, lane);
   const bool alive = pg.valid && s.alive;
   if (alive && !(kAblate && (b.debug & 8))) shade_bounce(bo, hn, hp, s);
-  emit_survivors(res, alive, s, pg.slot, qbase, out);
+  df.s = s;
+  df.slot = pg.slot;
+  df.alive = alive;
+  df.any = df.res.live != 0;
 }
 
 // ── depth 0 fused: generateRayFromCamera + computeIntersections + shadeAndExtendRays ────────
@@ -1264,7 +1205,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
       cam_top[2 * e + 1] = make_float4(t.bmax[1] - cp.y, t.bmax[2] - cp.z, __int_as_float(t.idx), __int_as_float(t.link));
     }
     for (int gi = threadIdx.x; TABLES_IN_LDS && gi < sc.num_geoms; gi += blockDim.x) {
-      const f3 q = mulMV<1>(sc.geoms[gi].inv, cp);
+      const f3 q = Ar<kD0>::xf_point(sc.geoms[gi].inv, cp);
       cam_qo[3 * gi] = q.x, cam_qo[3 * gi + 1] = q.y, cam_qo[3 * gi + 2] = q.z;
     }
   }
@@ -1296,6 +1237,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N, inv_w = 1.0f / (float)cam.res_x;
   const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+  Deferred df;
+  df.any = false;
   for (long long j = r; j < my_chunks; j += wq) {
     const long long gid = (j * qs.Q + q) * 64 + lane;
     const bool valid = gid < total;
@@ -1303,14 +1246,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     int k, pl;
     divmod(slot, b.N, inv_n, k, pl);
     const int p = global_pixel(b, pl);  // global pixel index
-    const f3 d = camera_dir(cam, inv_w, p);
+    const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p);
     // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
     // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
-    const bool near_scene = __ballot(valid && slab(o, ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+    const bool near_scene = __ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (near_scene) trace_group<true, TABLES_IN_LDS>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
+    if (near_scene) trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
     else w.best[lane] = kNoHit;
+    flush_deferred(df, qbase, out);  // the previous chunk's survivors (see Deferred)
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
     ShadeIO s;
@@ -1332,11 +1276,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, b, 0, k), p, ht, hmat, s);
     }
-    const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    df.res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
-    emit_survivors(res, alive, s, slot, qbase, out);
+    df.s = s;
+    df.slot = slot;
+    df.alive = alive;
+    df.any = df.res.live != 0;
   }
+  flush_deferred(df, qbase, out);
 }
 
 // ── depth >= 1 fused: computeIntersections + shadeAndExtendRays + compaction ───────────────
@@ -1399,8 +1347,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     return v;
   };
   In nx = load(r * 64 + lane);
+#define PT_TOUCH_PREFETCH()                                                                                         \
+  asm volatile("" ::"v"(nx.o.x), "v"(nx.o.y), "v"(nx.o.z), "v"(nx.d.x), "v"(nx.d.y), "v"(nx.d.z), "v"(nx.c.x), "v"(nx.c.y), \
+               "v"(nx.c.z), "v"(nx.slot))
+  PT_TOUCH_PREFETCH();  // same wait point as inside the loop, so that the loop header needs no vector-memory wait
   Pending pg;
   pg.any = false;
+  Deferred df;
+  df.any = false;
   int it = 0;
   int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
   for (int j = r; j * 64 < n_q; j += wq, ++it) {
@@ -1411,10 +1365,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     const int par = it & 1;
     cy.best[par * 64 + lane] = kNoHit;
     carry_search<!TABLES_IN_LDS>(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
-    if (pg.any) {  // the previous group: all of its candidates are resolved once the ring has passed its mark
-      carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-      shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, qbase, out, lane);
-    }
+    if (pg.any) carry_drain_to(cy, pg.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
+    // vmcnt is one in-order counter: waiting for the prefetched paths at the top of the next iteration would also wait
+    // for everything issued after them — this iteration's stores and the reservation atomic, i.e. a full memory round
+    // trip per group.  Touch the prefetched registers HERE instead, where everything outstanding (the prefetch and the
+    // previous group's reservation) is a whole candidate search old, so that this is the iteration's only vector-memory
+    // wait; the stores and the atomic below then have until the same point of the next iteration.
+    PT_TOUCH_PREFETCH();
+    flush_deferred(df, qbase, out);  // survivors of the group shaded one iteration ago
+    if (pg.any) shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
     pg.d = cur.d;
     pg.c = cur.c;
     pg.slot = cur.slot;
@@ -1423,9 +1382,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     pg.mark = cy.appended;
     pg.any = true;
   }
+  flush_deferred(df, qbase, out);
   if (pg.any) {
     carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-    shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, qbase, out, lane);
+    shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
+    flush_deferred(df, qbase, out);
   }
 }
 
@@ -1580,13 +1541,13 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       break;
     case kIntersect:
       if (in_lds)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true>, kBlock, round16(tbl) + kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true, false>, kBlock, round16(tbl) + kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
       else
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false>, kBlock, kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false, false>, kBlock, kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
       break;
     case kIntersectLegacy:
-      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true>, kBlock, round16(tbl));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false>, kBlock, 0);
+      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true, false>, kBlock, round16(tbl));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false, false>, kBlock, 0);
       break;
     case kPrimary:
       if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
@@ -1609,18 +1570,23 @@ void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const Batc
   hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, cam, b, qs, out, cnt0);
 }
 
+// exact_arith: the rays are primary rays (depth 0), traced with the reference's exact arithmetic in every mode
 void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
-                      ptd::PathBuf paths, ptd::HitBuf hits, bool legacy) {
+                      ptd::PathBuf paths, ptd::HitBuf hits, bool legacy, bool exact_arith) {
   const int bytes = table_bytes(sc);
   const bool in_lds = tables_in_lds(sc);
-  if (legacy) {
-    if (in_lds) hipLaunchKernelGGL(k_intersect_legacy<true>, dim3(grid), dim3(kBlock), round16(bytes), s, sc, qs, cnt_in, paths, hits);
-    else hipLaunchKernelGGL(k_intersect_legacy<false>, dim3(grid), dim3(kBlock), 0, s, sc, qs, cnt_in, paths, hits);
-    return;
-  }
+  const bool ex = kD0 && exact_arith;
   const int wave_lds = kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry);
-  if (in_lds) hipLaunchKernelGGL(k_intersect<true>, dim3(grid), dim3(kBlock), round16(bytes) + wave_lds, s, sc, qs, cnt_in, paths, hits);
-  else hipLaunchKernelGGL(k_intersect<false>, dim3(grid), dim3(kBlock), wave_lds, s, sc, qs, cnt_in, paths, hits);
+  const int lds = legacy ? (in_lds ? round16(bytes) : 0) : (in_lds ? round16(bytes) : 0) + wave_lds;
+#define PT_LAUNCH_ISECT(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), lds, s, sc, qs, cnt_in, paths, hits)
+  if (legacy) {
+    if (in_lds) { if (ex) PT_LAUNCH_ISECT((k_intersect_legacy<true, kD0>)); else PT_LAUNCH_ISECT((k_intersect_legacy<true, false>)); }
+    else { if (ex) PT_LAUNCH_ISECT((k_intersect_legacy<false, kD0>)); else PT_LAUNCH_ISECT((k_intersect_legacy<false, false>)); }
+  } else {
+    if (in_lds) { if (ex) PT_LAUNCH_ISECT((k_intersect<true, kD0>)); else PT_LAUNCH_ISECT((k_intersect<true, false>)); }
+    else { if (ex) PT_LAUNCH_ISECT((k_intersect<false, kD0>)); else PT_LAUNCH_ISECT((k_intersect<false, false>)); }
+  }
+#undef PT_LAUNCH_ISECT
 }
 
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,

@@ -8,6 +8,15 @@ REFERENCE semantics — the oracle in LIBM mode running the reference-literal lo
   (2) at <= 16 spp at least 99.8 % of the pixels within 1e-5 (absolute, averaged radiance) — the rest are hit/miss
       flips at silhouettes, which the survey measured at 0.08 % between two compilations of the reference itself;
   (3) PSNR >= 45 dB + 10 log10(spp / 8).
+Bound (2) was calibrated by the survey on the reference's own scenes.  Scenes with many small spheres are chaotic (a
+sphere bounce multiplies a direction difference by distance / radius), so there even the 1-ulp difference between glibc's
+and the portable sinf / cosf — two equally valid evaluations of the reference's source — changes more than 0.2 % of the
+pixels (stress_big 160x90 at 8 spp: 0.39 %).  For those scenes the bound is therefore 0.2 % + 3 x that noise floor,
+the floor being measured in the test itself (oracle PORTABLE vs oracle LIBM, CPU only); (1) and (3) stay absolute.
+
+Primary rays are traced with the reference's exact arithmetic in every mode (pt_kernels.hip, namespace ex): they are the
+same in every iteration of a pixel, so a tie broken differently there (the diagonals of a square cornell frame look
+exactly along the box's corner edges) would not average out.
 """
 import os
 
@@ -38,15 +47,24 @@ def gpu(scene_path, res, spp, arith, depth=8, **kw):
     return img
 
 
-def check_tolerance(img, ref, spp, what):
+def check_tolerance(img, ref, spp, what, floor=0.0):
+    """floor: fraction of pixels by which two valid evaluations of the reference (oracle PORTABLE vs LIBM) differ."""
     a, b = img / np.float32(spp), ref / np.float32(spp)
     assert np.isfinite(a).all(), what
-    within = float((np.abs(a - b).max(axis=1) <= 1e-5).mean())
+    off = float((np.abs(a - b).max(axis=1) > 1e-5).mean())
     db = psnr(a, b)
-    print(f"{what}: {100 * within:.3f} % of pixels within 1e-5, PSNR {db:.1f} dB")
-    assert within >= 0.998, (what, within)
+    print(f"{what}: {100 * off:.3f} % of pixels off by > 1e-5 (noise floor {100 * floor:.3f} %), PSNR {db:.1f} dB")
+    assert off <= 0.002 + 3 * floor, (what, off, floor)
     assert db >= 45.0 + 10 * np.log10(spp / 8), (what, db)
-    return within, db
+    return off, db
+
+
+def noise_floor(oracle, ref_libm, spp, **render_kw):
+    """Pixels that differ between the oracle's two math modes (same loop): what 1 ulp of sinf / cosf alone changes."""
+    oracle.set_math_mode(oracle.PORTABLE)
+    alt = oracle.render(1, spp, variant=oracle.LITERAL, **render_kw)
+    oracle.set_math_mode(oracle.LIBM)
+    return float((np.abs(alt / np.float32(spp) - ref_libm / np.float32(spp)).max(axis=1) > 1e-5).mean())
 
 
 @pytest.mark.parametrize("arith", MODES)
@@ -62,7 +80,8 @@ def test_mode_within_stated_tolerance_of_reference_semantics(scene_dir, oracle, 
     oracle.set_math_mode(oracle.LIBM)
     oracle.load_scene(scene_dir[scene], res=res)
     ref = oracle.render(1, spp, depth=depth, variant=oracle.LITERAL, nthreads=16)
-    check_tolerance(img, ref, spp, f"{arith} {scene} {res} {spp} spp")
+    floor = noise_floor(oracle, ref, spp, depth=depth, nthreads=16) if scene.startswith("stress") else 0.0
+    check_tolerance(img, ref, spp, f"{arith} {scene} {res} {spp} spp", floor)
 
 
 @pytest.mark.parametrize("arith", MODES)
@@ -76,10 +95,13 @@ def test_mode_c5_rows_within_tolerance(oracle, tmp_path, arith):
     oracle.set_math_mode(oracle.LIBM)
     oracle.load_scene(path, res=(w, h))
     rows = (300, 540, 900)
-    ref = np.concatenate([oracle.render(1, spp, depth=8, variant=oracle.LITERAL, nthreads=min(16, os.cpu_count() or 1),
-                                        pix_begin=r * w, pix_count=w) for r in rows])
+    nt = min(16, os.cpu_count() or 1)
+    ref = np.concatenate([oracle.render(1, spp, depth=8, variant=oracle.LITERAL, nthreads=nt, pix_begin=r * w, pix_count=w) for r in rows])
+    oracle.set_math_mode(oracle.PORTABLE)
+    alt = np.concatenate([oracle.render(1, spp, depth=8, variant=oracle.LITERAL, nthreads=nt, pix_begin=r * w, pix_count=w) for r in rows])
+    floor = float((np.abs(alt / np.float32(spp) - ref / np.float32(spp)).max(axis=1) > 1e-5).mean())
     got = np.concatenate([img[r * w:(r + 1) * w] for r in rows])
-    check_tolerance(got, ref, spp, f"{arith} C5 rows {rows}")
+    check_tolerance(got, ref, spp, f"{arith} C5 rows {rows}", floor)
 
 
 @pytest.mark.parametrize("arith", MODES)
@@ -93,7 +115,8 @@ def test_mode_random_scenes_within_tolerance(oracle, tmp_path, arith):
         oracle.set_math_mode(oracle.LIBM)
         oracle.load_scene(path, res=res)
         ref = oracle.render(1, spp, depth=8, variant=oracle.LITERAL, nthreads=16)
-        check_tolerance(img, ref, spp, f"{arith} random scene {seed}")
+        floor = noise_floor(oracle, ref, spp, depth=8, nthreads=16)
+        check_tolerance(img, ref, spp, f"{arith} random scene {seed}", floor)
 
 
 @pytest.mark.parametrize("arith", MODES)
