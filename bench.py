@@ -6,19 +6,31 @@ Metric (BASELINE.json): Msamples/s (+ PSNR vs the 5000-spp image), cornell.txt 1
   --steps K = K iterations accumulated (default 5000 = BASELINE configs[2]);
   value     = W*H*K / wall seconds of the render loop incl. compaction, gather and the final
               image gather, scene already resident on the GPU.
-N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL); the framebuffer is cut
-into N row tiles with GLOBAL pixel indices (so every sample is the same sample as on one GPU),
-no collective on the data path, one RCCL gather of the float tiles at image write-out.
+N GPUs: one process per GPU (torch.distributed, backend nccl == RCCL); the framebuffer is cut into
+row-interleaved tiles with GLOBAL pixel indices (so every sample is the same sample as on one GPU), no
+collective on the data path, one RCCL gather of the float tiles at image write-out.  (The C++ single-process
+form of the same partition is pt_group_* / `pt_render --gpus K`.)
+
+Arithmetic mode (--arith, PT_ARITH_* in include/pt_amd.h): the timed run uses `fast` by default — same
+algorithm, draws and decisions as the reference, f32 throughout, held to the stated tolerance against the
+reference semantics by tests/test_gpu_arith.py; `modes` reports exact (bit-identical to the oracle) and fma
+from the same process.
 
 Extra objects on the JSON line:
-  roofline     computeIntersections: 56 B per live ray (24 B read o,d + 32 B written t,n,mat,p;
-               SURVEY.md §8d) x live rays traced / HIP-event time of those launches (events recorded
-               by the library on its own render stream during the timed region) vs 8 TB/s HBM.
-  cpu_baseline the oracle (kind "port": oracle/pt_oracle.cpp, reference-literal loop, libm math)
-               timed on ONE host thread on a bounded sample of the same workload (rank 0, N=1 only).
-  psnr         (N=1 only, outside the timed region) PSNR of 16/64/256/1000-spp prefixes against the
-               K-spp image, and the cross-implementation check of a few full-resolution rows
-               against the CPU oracle at the full sample count.
+  roofline       dominant kernel k_bounce (computeIntersections + shadeAndExtendRays + compaction, depths >= 1):
+                 algorithmic bytes (40 B read + 40 B per survivor / 12 B per retired sample written) / HIP-event
+                 time of those launches (events recorded by the library on its own render stream inside the
+                 timed region) vs 8 TB/s; `traffic` = HBM bytes per launch from the committed PMC passes
+                 (profiles/dominant_kernel_traffic.json holds bytes PER RAY for this arithmetic mode) scaled by
+                 this run's rays per launch.
+  roofline_valu  what actually bounds that kernel: vector-ALU instruction issue (one wave64 instruction per 4
+                 cycles per SIMD).  VALU instructions per 64-ray group and the pipe's busy fraction from the
+                 committed PMC summary, and the issue rate this run achieved against the 4-cycle peak.
+  cpu_baseline   the oracle (kind "port": oracle/pt_oracle.cpp, reference-literal loop, libm math)
+                 timed on ONE host thread on a bounded sample of the same workload (rank 0, N=1 only).
+  psnr           (N=1 only, outside the timed region) PSNR of 16/64/256/1000-spp prefixes against a 5000-spp
+                 GPU image; on a row subset the same PSNRs for the reference semantics (oracle, LIBM) against
+                 ITS 5000-spp rows, and their difference (north_star: within 0.1 dB).
 """
 from __future__ import annotations
 
@@ -37,7 +49,10 @@ import numpy as np
 
 W, H, DEPTH = 1920, 1080, 8
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-ISECT_BYTES_PER_RAY = 56
+ISECT_BYTES_PER_RAY = 56       # SURVEY.md §8(d), unfused computeIntersections
+REF_SPP = 5000                 # BASELINE: PSNR vs the 5000-spp image
+SIMDS_PER_CU = 4
+VALU_CYCLES_PER_WAVE_INSTR = 4  # wave64 on a 16-lane SIMD (non-packed f32 peak 78.6 TFLOP/s = 256 CUs x 4 x 16 x 2 x 2.4 GHz)
 
 
 def psnr(a: np.ndarray, b: np.ndarray) -> float:
@@ -61,9 +76,17 @@ def cpu_baseline(scene_path: str, seconds_target: float = 15.0) -> dict:
     for r in idx:
         ob.render(1, spp, depth=DEPTH, variant=ob.LITERAL, nthreads=1, pix_begin=r * W, pix_count=W)
     dt = time.perf_counter() - t0
-    return {"value": rows * W * spp / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+    return {"value": round(rows * W * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": f"cornell 1920x1080 depth 8: {rows} full rows (every 20th) x {spp} spp, "
                       f"reference-literal loop, {dt:.1f} s on 1 of {os.cpu_count()} host threads"}
+
+
+def bounce_accounting(st):
+    """Algorithmic bytes and rays of the timed k_bounce launches from the renderer's live-ray statistics."""
+    live = np.array(st.live_rays[:DEPTH], dtype=np.float64)
+    nxt = np.append(live[1:], 0.0)  # survivors of depth d = live rays of depth d+1 (none after the last depth)
+    alg = float((40 * live[1:] + 40 * nxt[1:] + 12 * (live[1:] - nxt[1:])).sum())
+    return live, alg, float(live[1:].sum())
 
 
 def main() -> None:
@@ -71,6 +94,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--arith", choices=["exact", "fma", "fast"], default="fast", help="arithmetic mode of the timed run (PT_ARITH_*)")
     ap.add_argument("--iters-per-batch", type=int, default=0)
     ap.add_argument("--queues", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
@@ -79,9 +103,9 @@ def main() -> None:
     ap.add_argument("--contiguous-tiles", action="store_true", help="A/B: one block of rows per rank instead of interleaved rows")
     ap.add_argument("--unfused-bounces", action="store_true", help="A/B: depths >= 1 as separate intersect + shade launches")
     ap.add_argument("--debug-flags", type=int, default=0, help="A/B switches (16 / 32: result-neutral; 1-8 need a -DPT_ABLATE library)")
-    ap.add_argument("--arith", choices=["exact", "fma", "fast"], default="fast", help="arithmetic mode of the kernels (PT_ARITH_*)")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket intersect launches with HIP events")
-    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and psnr (N=1 extras)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel's launches with HIP events")
+    ap.add_argument("--no-extras", action="store_true", help="skip modes, cpu_baseline and psnr (N=1 extras)")
+    ap.add_argument("--stress", action="store_true", help="second JSON line: BASELINE config C5 (10,170 primitives, 1080p)")
     ap.add_argument("--save", type=str, default="", help="write the final image as PREFIX.png/.pfm")
     args = ap.parse_args()
 
@@ -127,12 +151,13 @@ def main() -> None:
     count = topt["pixel_count"]
     tile = torch.zeros((count, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
-    def make_renderer(time_kernels: bool):
-        return capi.Renderer(scene, device=local_rank, **topt,
-                             iters_per_batch=args.iters_per_batch, num_queues=args.queues,
-                             blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels,
-                             legacy_traversal=args.legacy_traversal, debug_flags=args.debug_flags, arith=args.arith,
-                             unfused_primary=args.unfused_primary, unfused_bounces=args.unfused_bounces)
+    def make_renderer(time_kernels: bool, arith: str = args.arith, **over):
+        kw = dict(device=local_rank, **topt, iters_per_batch=args.iters_per_batch, num_queues=args.queues,
+                  blocks_per_cu=args.blocks_per_cu, time_kernels=time_kernels, legacy_traversal=args.legacy_traversal,
+                  debug_flags=args.debug_flags, arith=arith, unfused_primary=args.unfused_primary,
+                  unfused_bounces=args.unfused_bounces)
+        kw.update(over)
+        return capi.Renderer(scene, **kw)
 
     def barrier():
         if world > 1:
@@ -161,20 +186,15 @@ def main() -> None:
         dt = float(tmax.item())
 
     st = r.stats()
-    live = np.array(st.live_rays[:DEPTH], dtype=np.float64)
-    timed = live[1:] if st.primary_fused else live  # depths covered by the timed computeIntersections launches
+    live, alg_bytes, units = bounce_accounting(st)
     isect_s = st.intersect_ms / 1e3
-    if world > 1:  # roofline is per GPU: report rank 0's kernel (all ranks run the same kernel on their tile)
-        pass
-    roofline = None
+    roofline = roofline_valu = None
     if st.intersect_launches > 0 and isect_s > 0:
-        nxt = np.append(live[1:], 0.0)  # survivors of depth d = live rays of depth d+1 (none after the last depth)
+        timed = live[1:] if st.primary_fused else live  # depths covered by the timed launches
         if st.bounces_fused:
             # fused bounce kernel, depths >= 1: 40 B path state read per ray; written: 40 B per survivor or
             # 12 B per retired sample (the hit record of SURVEY §8d's 56 + 104 B never reaches HBM)
             kernel = "k_bounce (computeIntersections + shadeAndExtendRays + compaction, depths 1..7)"
-            alg_bytes = float((40 * live[1:] + 40 * nxt[1:] + 12 * (live[1:] - nxt[1:])).sum())
-            units = float(live[1:].sum())
             per_unit = "40 B read + 40 B (survivor) / 12 B (retired) written per ray"
         else:
             kernel = "k_intersect (computeIntersections)"
@@ -182,23 +202,40 @@ def main() -> None:
             units = float(timed.sum())
             per_unit = "56 B per live ray (24 read + 32 written)"
         achieved = alg_bytes / isect_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
-        if os.path.exists(tpath):
+        rays_per_launch = units / st.intersect_launches
+        avg_us = isect_s * 1e6 / st.intersect_launches
+        prof = {}
+        ppath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+        if os.path.exists(ppath):
             try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel", "").split(" ")[0] == kernel.split(" ")[0]:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                prof = json.load(open(ppath)).get(args.arith, {})
             except Exception:
-                traffic = None
+                prof = {}
+        same_kernel = prof.get("kernel", "").split(" ")[0] == kernel.split(" ")[0]
+        traffic = round(prof["hbm_bytes_per_ray"] * rays_per_launch) if same_kernel and "hbm_bytes_per_ray" in prof else None
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "launches": int(st.intersect_launches), "avg_launch_us": round(isect_s * 1e6 / st.intersect_launches, 3),
+                    "traffic_source": (f"profiles/dominant_kernel_traffic.json [{args.arith}]: {prof['hbm_bytes_per_ray']:.1f} B/ray "
+                                       f"(2 x FETCH_SIZE + WRITE_SIZE) x this run's rays per launch") if traffic else None,
+                    "launches": int(st.intersect_launches), "avg_launch_us": round(avg_us, 3),
                     "algorithmic_bytes_per_launch": round(alg_bytes / st.intersect_launches, 1),
                     "algorithmic_bytes_per_unit": per_unit,
-                    "rays_per_launch": round(units / st.intersect_launches, 1),
+                    "rays_per_launch": round(rays_per_launch, 1),
                     "depths_timed": "1..7 (depth 0 runs in the fused primary kernel)" if st.primary_fused else "0..7",
                     "live_rays_per_sample": round(float(live.sum()) / max(1, st.samples), 4)}
+        if same_kernel and "valu_per_group" in prof:
+            # measured bound: VALU issue.  groups/launch x VALU/group wave-instructions over (CUs x 4 SIMDs) in avg_us
+            groups = rays_per_launch / 64.0
+            rate = groups * prof["valu_per_group"] / (st.num_cus * SIMDS_PER_CU) / (avg_us * 1e-6)  # wave-instr/s/SIMD
+            clock = prof.get("shader_clock_ghz", 2.4) * 1e9
+            roofline_valu = {"bound": "valu", "kernel": kernel.split(" ")[0],
+                             "valu_per_64ray_group": prof["valu_per_group"], "salu_per_64ray_group": prof.get("salu_per_group"),
+                             "valu_busy_frac_pmc": prof.get("valu_busy_frac"),
+                             "achieved": round(rate / 1e6, 1), "peak": round(clock / VALU_CYCLES_PER_WAVE_INSTR / 1e6, 1),
+                             "unit": "M wave-instructions/s per SIMD", "frac": round(rate / (clock / VALU_CYCLES_PER_WAVE_INSTR), 4),
+                             "source": f"profiles/dominant_kernel_traffic.json [{args.arith}] (PMC: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, "
+                                       f"SQ_BUSY_CYCLES) x this run's groups per launch / HIP-event time; peak = 1 wave64 "
+                                       f"instruction per {VALU_CYCLES_PER_WAVE_INSTR} cycles per SIMD at {clock / 1e9:.2f} GHz"}
 
     samples = float(W) * H * args.steps
     out = {
@@ -216,55 +253,92 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": f"cornell.txt 1920x1080, {args.steps} spp, depth 8, BVH + compaction, "
                                f"{world}x MI355X " + ("interleaved-row tiles" if striped else "row tiles") + (", one RCCL gather" if world > 1 else ""),
+                   "arith": args.arith,
                    "iters_per_batch": int(st.iters_per_batch), "queues": int(st.num_queues),
                    "grid_blocks": int(st.grid_blocks), "cus": int(st.num_cus),
                    "device_mem_mb": round(st.device_bytes / 2 ** 20, 1),
                    "kernel_events": not args.no_kernel_events,
                    "traversal": "legacy per-lane" if args.legacy_traversal else "wave-cooperative"},
         "roofline": roofline,
+        "roofline_valu": roofline_valu,
     }
-    # Context: the reference pipeline's own algorithmic traffic is 44 + 160*L + 40 B per sample
-    # (generate 44, intersect 56 + shade 104 per live segment, gather 40; L = live segments per sample), i.e. a
-    # ceiling of 8 TB/s / that figure if every stage streamed its records through HBM.  The fused kernels avoid
-    # most of that traffic, so the sample rate is also quoted as the HBM rate that pipeline would have needed.
-    L = float(live.sum()) / max(1, st.samples)
-    ref_bytes = 44.0 + 160.0 * L + 40.0
-    out["pipeline_equivalent"] = {"reference_pipeline_bytes_per_sample": round(ref_bytes, 1),
-                                  "equivalent_GBps": round(out["value"] * 1e6 * ref_bytes / 1e9 / max(1, world), 1),
-                                  "frac_of_hbm_peak_per_gpu": round(out["value"] * 1e6 * ref_bytes / 1e9 / max(1, world) / HBM_PEAK_GBS, 4)}
 
     if rank == 0 and world == 1 and not args.no_extras:
         img = full.cpu().numpy()
-        final_avg = img / np.float32(args.steps)
-        ps = {}
         r.free()
-        # prefixes of the same sample sequence (iterations 1..n), outside the timed region
+        # ---- the other arithmetic modes, same process, same workload (bounded: <= 1000 steps each) ----
+        modes = {args.arith: {"value": out["value"], "steps": args.steps,
+                              "k_bounce_us": roofline["avg_launch_us"] if roofline else None,
+                              "hbm_frac": roofline["frac"] if roofline else None}}
+        msteps = min(args.steps, 1000)
+        for m in ("exact", "fma", "fast"):
+            if m in modes:
+                continue
+            rr = make_renderer(True, arith=m)
+            rr.render(1, min(args.warmup, 50) or 1)
+            rr.readback_device(tile.data_ptr())
+            rr.free()
+            rr = make_renderer(True, arith=m)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rr.render(1, msteps)
+            rr.readback_device(tile.data_ptr())
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            s1 = rr.stats()
+            _, a1, _ = bounce_accounting(s1)
+            modes[m] = {"value": round(W * H * msteps / d1 / 1e6, 3), "steps": msteps,
+                        "k_bounce_us": round(s1.intersect_ms * 1e3 / max(1, s1.intersect_launches), 3),
+                        "hbm_frac": round(a1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None}
+            rr.free()
+        out["modes"] = modes
+
+        # ---- PSNR vs the 5000-spp image (always 5000, whatever --steps), outside the timed region ----
+        def render_sum(n, arith=args.arith):
+            rr = capi.Renderer(scene, device=local_rank, arith=arith)
+            rr.render(1, n)
+            a = rr.readback()
+            rr.free()
+            return a
+        ref = img if args.steps == REF_SPP else render_sum(REF_SPP)
+        ref_avg = ref / np.float32(REF_SPP)
+        ps = {}
+        prefixes = {}
         for n in (16, 64, 256, 1000):
-            if n < args.steps:
-                rr = capi.Renderer(scene, device=local_rank)
-                rr.render(1, n)
-                ps[f"{n}spp_vs_{args.steps}spp"] = round(psnr(rr.readback() / np.float32(n), final_avg), 2)
-                rr.free()
-        # cross-implementation check at the full sample count on whole rows
+            prefixes[n] = render_sum(n)
+            ps[f"{n}spp_vs_{REF_SPP}spp"] = round(psnr(prefixes[n] / np.float32(n), ref_avg), 2)
+        # ---- the same against the reference semantics (oracle, LIBM math, reference-literal loop) on whole rows ----
         from oracle import binding as ob
-        rows = [540, 800] if args.steps >= 1000 else [100, 540, 800, 1079]
-        threads = min(16, os.cpu_count() or 1)
-        exact = True
-        a_rows, l_rows = [], []
-        for row in rows:
+        rows = [540, 800]
+        threads = min(32, os.cpu_count() or 1)
+        ob.set_math_mode(ob.LIBM)
+        ob.load_scene(scene_path, res=(W, H))
+
+        def oracle_rows(n):
+            return np.concatenate([ob.render(1, n, depth=DEPTH, variant=ob.LITERAL, nthreads=threads, pix_begin=row * W, pix_count=W)
+                                   for row in rows])
+
+        def gpu_rows(a):
+            return np.concatenate([a[row * W:(row + 1) * W] for row in rows])
+        o_ref = oracle_rows(REF_SPP) / np.float32(REF_SPP)
+        g_ref = gpu_rows(ref) / np.float32(REF_SPP)
+        ps["rows_checked"] = rows
+        ps[f"gpu_{REF_SPP}spp_vs_reference_semantics_{REF_SPP}spp_db"] = round(psnr(g_ref, o_ref), 2)
+        delta = {}
+        for n in (16, 64, 256, 1000):
+            p_gpu = psnr(gpu_rows(prefixes[n]) / np.float32(n), o_ref)
+            p_orc = psnr(oracle_rows(n) / np.float32(n), o_ref)
+            delta[f"{n}spp"] = {"gpu_db": round(p_gpu, 3), "reference_semantics_db": round(p_orc, 3), "delta_db": round(abs(p_gpu - p_orc), 4)}
+        ps["psnr_delta_vs_oracle_db"] = delta
+        ps["max_delta_db"] = max(v["delta_db"] for v in delta.values())
+        ps["within_0.1_db"] = bool(ps["max_delta_db"] <= 0.1)
+        if args.arith == "exact":
             ob.set_math_mode(ob.PORTABLE)
             ob.load_scene(scene_path, res=(W, H))
-            ref = ob.render(1, args.steps, depth=DEPTH, variant=ob.RETIRE, nthreads=threads, pix_begin=row * W, pix_count=W)
-            got = img[row * W:(row + 1) * W]
-            exact = exact and bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
-            ob.set_math_mode(ob.LIBM)
-            ref_l = ob.render(1, args.steps, depth=DEPTH, variant=ob.LITERAL, nthreads=threads, pix_begin=row * W, pix_count=W)
-            a_rows.append(got / np.float32(args.steps))
-            l_rows.append(ref_l / np.float32(args.steps))
-        ps["rows_checked"] = rows
-        ps["gpu_bit_exact_vs_oracle_portable"] = exact
-        ps["gpu_vs_reference_semantics_libm_db"] = round(psnr(np.concatenate(a_rows), np.concatenate(l_rows)), 2)
+            exact_rows = np.concatenate([ob.render(1, args.steps, depth=DEPTH, variant=ob.RETIRE, nthreads=threads, pix_begin=row * W, pix_count=W) for row in rows])
+            ps["gpu_bit_exact_vs_oracle_portable"] = bool(np.array_equal(gpu_rows(img).view(np.uint32), exact_rows.view(np.uint32)))
         out["psnr"] = ps
+        assert ps["within_0.1_db"], f"PSNR differs from the reference semantics by {ps['max_delta_db']} dB (> 0.1)"
         out["cpu_baseline"] = cpu_baseline(scene_path)
         if args.save:
             capi.save_png(args.save + ".png", img, W, H, float(args.steps))
@@ -273,7 +347,13 @@ def main() -> None:
         r.free()
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+    if args.stress and rank == 0 and world == 1:
+        # optional second line: BASELINE config C5 (tools/run_config.py stress), 200 spp by default
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import run_config
+        print(json.dumps(run_config.run("stress", spp=200, arith=args.arith)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -276,6 +276,7 @@ ptk::SceneTables tables(const Ctx& g) {
   t.cull_margin = (g.debug_flags & 16) ? INFINITY : g.cull_margin;
   t.top_xor = (g.debug_flags & 32) ? 0ull : g.top_xor;
   t.lds_table_bytes = g.lds_table_bytes;
+  t.max_batch_iters = g.K;
   return t;
 }
 

@@ -12,8 +12,6 @@ constexpr int kLdsTableBytes = 64 * 1024;  // upper limit for staging the scene 
 constexpr int kMaxTop = 32;                // entries in the flattened BVH top (per-lane 32-bit subtree mask)
 constexpr int kCandCap = 192;              // per-wave candidate list entries (LDS)
 constexpr int kWaveLds = 64 * 8 + 7 * 64 * 4 + kCandCap * 4;  // best keys + winner records + list = 3072 B
-// fused kernels: double-buffered keys/records + candidate ring with rays (see Carry) = 7680 B per wave
-constexpr int kWaveLds2 = 2 * 64 * 8 + 2 * 6 * 64 * 4 + 128 * 4 + 6 * 128 * 4 + 64 * 4;
 
 struct SceneTables {
   const ptd::Node* nodes;  // threaded DFS order
@@ -37,6 +35,9 @@ struct SceneTables {
   // Host-side decision (KernelApi::auto_lds_table_limit): nodes + geoms up to this many bytes are staged in LDS by
   // the traversal kernels; -1: never.  Part of the tables so that several renderer contexts can differ.
   int32_t lds_table_bytes;
+  // Iterations per wavefront batch of the context (>= every BatchInfo::K it launches): sizes the per-iteration RNG hash
+  // table in LDS (none beyond 256 iterations, those batches hash per ray).
+  int32_t max_batch_iters;
 };
 
 struct BatchInfo {

@@ -32,6 +32,8 @@
 
 #include <float.h>
 
+#include <type_traits>
+
 #include "pt_portable_math.h"
 
 #ifndef PT_ARITH
@@ -97,6 +99,16 @@ constexpr bool kAblate = false;
 #define PT_STEAL_MIN 16
 #endif
 constexpr int kStealMin = PT_STEAL_MIN;  // idle lanes needed before a work-stealing step is run (65: never)
+// Waves per SIMD the fused kernels are compiled for (__launch_bounds__ second argument).  5 would cap them at 96 VGPRs
+// (1-5 spilled) and, with the trimmed per-wave LDS block, fit a fifth workgroup per CU for cornell-sized scenes; measured
+// in-box (tools/build_variant.sh + tools/ab_libs.sh): k_bounce 322 -> 351 us (fast), 363 -> 422 us (exact).  So 4.
+#ifndef PT_BOUNCE_WAVES
+#define PT_BOUNCE_WAVES 4
+#endif
+#ifndef PT_PRIMARY_WAVES
+#define PT_PRIMARY_WAVES 4
+#endif
+constexpr int kBounceWaves = PT_BOUNCE_WAVES, kPrimaryWaves = PT_PRIMARY_WAVES;
 
 struct f3 {
   float x, y, z;
@@ -218,13 +230,17 @@ struct MinStd {
 // The first factor depends only on (iteration, depth): the kernels compute it once per iteration of the batch into
 // a small LDS table instead of once per ray (same values, ~18 VALU less per ray).
 PT_DEV uint32_t iter_hash(int iter, int depth) { return utilhash((1u << 31) | ((uint32_t)depth << 22) | (uint32_t)iter); }
-constexpr int kIterHashMax = 256;  // table entries (iterations per batch it covers; larger batches hash per ray)
-PT_DEV void iter_hash_fill(uint32_t* tab, const BatchInfo& b, int depth) {  // before the kernel's __syncthreads()
-  if (b.K <= kIterHashMax)
+constexpr int kIterHashMax = 256;  // most table entries (iterations per batch it covers; larger batches hash per ray)
+// LDS entries of the table: the context's iterations per batch (SceneTables::max_batch_iters), none beyond kIterHashMax
+__host__ __device__ inline int iter_hash_entries(const SceneTables& sc) {
+  return sc.max_batch_iters <= kIterHashMax ? (sc.max_batch_iters + 3) & ~3 : 0;
+}
+PT_DEV void iter_hash_fill(uint32_t* tab, const SceneTables& sc, const BatchInfo& b, int depth) {  // before the kernel's __syncthreads()
+  if (iter_hash_entries(sc) > 0)
     for (int i = threadIdx.x; i < b.K; i += blockDim.x) tab[i] = iter_hash(b.iter_first + i, depth);
 }
-PT_DEV uint32_t iter_hash_of(const uint32_t* tab, const BatchInfo& b, int depth, int k) {
-  return b.K <= kIterHashMax ? tab[k] : iter_hash(b.iter_first + k, depth);
+PT_DEV uint32_t iter_hash_of(const uint32_t* tab, const SceneTables& sc, const BatchInfo& b, int depth, int k) {
+  return iter_hash_entries(sc) > 0 ? tab[k] : iter_hash(b.iter_first + k, depth);
 }
 
 // ───────────────────────────── LDS staging ─────────────────────────────────
@@ -885,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   extern __shared__ float4 lds_raw[];
   stage16(lds_raw, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
   uint32_t* ihash = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_raw) + ((sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15));
-  iter_hash_fill(ihash, b, depth);
+  iter_hash_fill(ihash, sc, b, depth);
   __syncthreads();
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds_raw);
 
@@ -933,7 +949,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     if (valid) {
       int k, p;
       divmod(slot, b.N, inv_n, k, p);
-      bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, b, depth, k), global_pixel(b, p), cur.ht, cur.hmat, s);
+      bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, sc, b, depth, k), global_pixel(b, p), cur.ht, cur.hmat, s);
     }
     const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
@@ -954,33 +970,43 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
 // filled up in between).  Order of evaluation still does not matter: the (t, leaf) key minimum is the
 // reference's choice.
 constexpr int kRing = 128;  // ring entries per wave (power of two; <= 63 pending + <= 64 appended at once)
+// SMALL: the LDS-table kernels (every leaf is one of <= 32 top entries, so leaf indices are < 64): 16-bit ring entries and
+// no work-stealing table — 7424 B per wave instead of 7936, which is what lets a fifth workgroup of k_bounce fit a CU.
+template <bool SMALL>
 struct Carry {
+  using Ent = typename std::conditional<SMALL, uint16_t, uint32_t>::type;
   unsigned long long* best;  // [2][64]
   float* rec;                // [2][6][64]  normal xyz, point xyz
-  uint32_t* ent;             // [kRing]     (leaf << 7) | (parity << 6) | owner lane
+  Ent* ent;                  // [kRing]     (leaf << 7) | (parity << 6) | owner lane
   float* ray;                // [2][6][64]  origin xyz, direction xyz of each lane's ray, by group parity
-  int* slot;                 // [64]        scratch of the work-stealing step (carry_search)
+  int* slot;                 // [64]        scratch of the work-stealing step (carry_search); not SMALL only
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
   int debug;                 // BatchInfo::debug
 };
-PT_DEV Carry carry_init(char* base) {
-  Carry c;
+template <bool SMALL>
+__host__ __device__ constexpr int carry_bytes() {
+  return 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * (SMALL ? 2 : 4) + 2 * 6 * 64 * 4 + (SMALL ? 0 : 64 * 4);
+}
+template <bool SMALL>
+PT_DEV Carry<SMALL> carry_init(char* base) {
+  Carry<SMALL> c;
   c.best = reinterpret_cast<unsigned long long*>(base);
   c.rec = reinterpret_cast<float*>(base + 2 * 64 * 8);
-  c.ent = reinterpret_cast<uint32_t*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4);
-  c.ray = reinterpret_cast<float*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4);
-  c.slot = reinterpret_cast<int*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * 4 + 2 * 6 * 64 * 4);
+  c.ray = reinterpret_cast<float*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4);
+  c.ent = reinterpret_cast<typename Carry<SMALL>::Ent*>(base + 2 * 64 * 8 + 2 * 2 * 6 * 64 * 4);
+  c.slot = reinterpret_cast<int*>(base + 2 * 64 * 8 + 2 * 2 * 6 * 64 * 4 + kRing * 4);
   c.head = c.count = c.appended = c.processed = 0;
   c.debug = 0;
   return c;
 }
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
-PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__ nodes,
+template <bool SMALL>
+PT_DEV void carry_chunk(Carry<SMALL>& c, int n, int lane, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
   const int idx = (c.head + lane) & (kRing - 1);
-  const uint32_t entry = c.ent[idx];
+  const uint32_t entry = (uint32_t)c.ent[idx];
   const int src = (int)(entry & 63u);
   const int par = (int)((entry >> 6) & 1u);
   const uint32_t leaf = entry >> 7;
@@ -1008,14 +1034,15 @@ PT_DEV void carry_chunk(Carry& c, int n, int lane, const ptd::Node* __restrict__
 }
 // Append the lanes with `pass` (entry: leaf index, group parity, lane that owns the ray); runs a chunk as soon
 // as 64 entries are pending.  Wave-uniform control flow.
-PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner, int lane,
+template <bool SMALL>
+PT_DEV void carry_append(Carry<SMALL>& c, bool pass, uint32_t leaf, int par, int owner, int lane,
                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const unsigned long long m = __ballot(pass);
   if (!m) return;
   const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   if (pass) {
     const int idx = (c.head + c.count + rank) & (kRing - 1);
-    c.ent[idx] = (leaf << 7) | ((uint32_t)par << 6) | (uint32_t)owner;
+    c.ent[idx] = (typename Carry<SMALL>::Ent)((leaf << 7) | ((uint32_t)par << 6) | (uint32_t)owner);
   }
   const int cnt = __popcll(m);
   c.count += cnt;
@@ -1026,7 +1053,7 @@ PT_DEV void carry_append(Carry& c, bool pass, uint32_t leaf, int par, int owner,
 // SUB: the scene has subtrees below the top list.  The LDS-table kernels are only used for scenes whose leaves all
 // fit the top list (auto_lds_table_limit), so their instantiation drops the subtree scan.
 template <bool SUB>
-PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
+PT_DEV void carry_search(Carry<!SUB>& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
                          unsigned long long top_xor) {
   const RayInv ri = ray_inv(d, o);
@@ -1061,7 +1088,7 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
         const int te = __builtin_ctz(mask);
         mask &= mask - 1u;
         const uint32_t leaf = __float_as_uint(reinterpret_cast<const float*>(top)[8 * te + 6]);  // TopEntry::idx
-        c.ent[(c.head + c.count + rank) & (kRing - 1)] = (leaf << 7) | tag;
+        c.ent[(c.head + c.count + rank) & (kRing - 1)] = (typename Carry<!SUB>::Ent)((leaf << 7) | tag);
       }
       const int cnt = __popcll(m);
       c.count += cnt;
@@ -1110,7 +1137,8 @@ PT_DEV void carry_search(Carry& c, const float4* top, int ntop, const ptd::Node*
 }
 // Make sure everything appended up to `mark` has been tested (only runs a partial chunk when the ring
 // did not fill up since).
-PT_DEV void carry_drain_to(Carry& c, int mark, int lane, const ptd::Node* __restrict__ nodes,
+template <bool SMALL>
+PT_DEV void carry_drain_to(Carry<SMALL>& c, int mark, int lane, const ptd::Node* __restrict__ nodes,
                            const ptd::Geom* __restrict__ geoms) {
   while (c.processed - mark < 0) carry_chunk(c, min(64, c.count), lane, nodes, geoms);
 }
@@ -1124,7 +1152,8 @@ struct Pending {
   bool any;  // wave-uniform: a group is pending
 };
 // Shading + retirement + compaction of a pending group from its resolved hit keys/records.
-PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
+template <bool SMALL>
+PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
                           const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
                           int depth, float inv_n, float4* __restrict__ final_rgba,
                           int32_t* __restrict__ counter, Deferred& df, int lane) {
@@ -1150,7 +1179,7 @@ PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __
     }
     int k, p;
     divmod(pg.slot, b.N, inv_n, k, p);
-    bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, b, depth, k), global_pixel(b, p), ht, hmat, s);
+    bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, sc, b, depth, k), global_pixel(b, p), ht, hmat, s);
   }
   df.res = retire_and_reserve(pg.valid, s, pg.slot, final_rgba, counter, lane);
   const bool alive = pg.valid && s.alive;
@@ -1169,7 +1198,7 @@ PT_DEV void shade_pending(const Carry& cy, const Pending& pg, const ptd::Mat* __
 // written + 24 B read, 32 B hit record written + read, 28 B path state re-read) at the one depth
 // where every sample is alive.  Also writes the per-queue sample counts of depth 0 (statistics).
 template <bool TABLES_IN_LDS>
-__global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
+__global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
                                                     int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
                                                     ptd::PathBuf out, float4* __restrict__ final_rgba) {
   extern __shared__ float4 lds_raw[];
@@ -1192,10 +1221,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
     tbl += nb_nodes + nb_geoms;
   }
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveLds);  // after the per-wave blocks
-  iter_hash_fill(ihash, b, 0);
+  iter_hash_fill(ihash, sc, b, 0);
   // camera-relative copies for the primary rays: top-list boxes minus the camera position and (tables in LDS only)
   // the camera position in each geom's object space — the same float operations the per-ray code would execute
-  float4* cam_top = reinterpret_cast<float4*>(ihash + kIterHashMax);
+  float4* cam_top = reinterpret_cast<float4*>(ihash + iter_hash_entries(sc));
   float* cam_qo = reinterpret_cast<float*>(cam_top + 2 * sc.num_top);
   {
     const f3 cp = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
@@ -1274,7 +1303,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
         hn = mk(w.rec[0 * 64 + lane], w.rec[1 * 64 + lane], w.rec[2 * 64 + lane]);
         hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
       }
-      bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, b, 0, k), p, ht, hmat, s);
+      bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k), p, ht, hmat, s);
     }
     df.res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
@@ -1295,7 +1324,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(SceneTables sc, ptd::Came
 // HBM-bound (5.1 TB/s measured) while k_intersect is VALU-bound, so fusing lets the shading traffic
 // overlap the search instead of following it.
 template <bool TABLES_IN_LDS>
-__global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
+__global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                    const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
                                                    ptd::PathBuf in, ptd::PathBuf out, float4* __restrict__ final_rgba) {
   extern __shared__ float4 lds_raw[];
@@ -1318,11 +1347,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
     tbl += nb_nodes + nb_geoms;
   }
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveLds2);  // after the per-wave blocks
-  iter_hash_fill(ihash, b, depth);
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * carry_bytes<TABLES_IN_LDS>());  // after the per-wave blocks
+  iter_hash_fill(ihash, sc, b, depth);
   __syncthreads();
   const int wib = threadIdx.x >> 6;
-  Carry cy = carry_init(lds + tbl + wib * kWaveLds2);
+  Carry<TABLES_IN_LDS> cy = carry_init<TABLES_IN_LDS>(lds + tbl + wib * carry_bytes<TABLES_IN_LDS>());
   cy.debug = b.debug;
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
@@ -1373,7 +1402,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
     // wait; the stores and the atomic below then have until the same point of the next iteration.
     PT_TOUCH_PREFETCH();
     flush_deferred(df, qbase, out);  // survivors of the group shaded one iteration ago
-    if (pg.any) shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
+    if (pg.any) shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
     pg.d = cur.d;
     pg.c = cur.c;
     pg.slot = cur.slot;
@@ -1385,7 +1414,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bounce(SceneTables sc, BatchInfo 
   flush_deferred(df, qbase, out);
   if (pg.any) {
     carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-    shade_pending(cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
+    shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
     flush_deferred(df, qbase, out);
   }
 }
@@ -1504,7 +1533,7 @@ inline int round16(int x) { return (x + 15) & ~15; }
 // ───────────────────────────── launch wrappers ─────────────────────────────
 int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false) {
   int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
-              kIterHashMax * 4;
+              iter_hash_entries(sc) * 4;
   if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
   if (primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + (in_lds ? round16(sc.num_geoms * 12) : 0);  // camera-relative copies
   return bytes;
@@ -1522,9 +1551,9 @@ int lds_table_limit(const SceneTables& sc, int forced_bytes) {
   const int tbl = table_bytes(sc);
   int with = 0, without = 0;
   if (tbl <= kLdsTableBytes && leaves_fit_top(sc) &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2)) != hipSuccess)
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>())) != hipSuccess)
     with = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2)) != hipSuccess)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>())) != hipSuccess)
     without = 1;
   (void)hipGetLastError();
   return (with >= without && with > 0) ? tbl : -1;
@@ -1554,11 +1583,11 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kBounce:
-      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds2));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds2));
+      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
       break;
     case kShade:
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kIterHashMax * 4);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
       break;
   }
   if (e != hipSuccess || n < 1) n = 1;
@@ -1597,14 +1626,14 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
 
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                    const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba) {
-  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
-  else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds2), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
+  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
+  else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, carry_bytes<false>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
 }
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
                   float4* final_rgba) {
-  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kIterHashMax * 4;
+  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4;
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
                      final_rgba);
 }

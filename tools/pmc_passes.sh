@@ -15,6 +15,6 @@ for grp in \
   "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$R/$OUT/pass$i" -o p -- python3 "$R/bench.py" --no-extras --no-kernel-events "$@" > "$R/$OUT/pass$i.json" 2> "$R/$OUT/pass$i.err" || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$R/$OUT/pass$i" -o p -- python3 "$R/bench.py" --no-extras "$@" > "$R/$OUT/pass$i.json" 2> "$R/$OUT/pass$i.err" || echo "pass $i failed"
 done
 ls -R "$R/$OUT" | head -40

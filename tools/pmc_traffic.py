@@ -1,29 +1,60 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of the dominant kernel from the FETCH_SIZE / WRITE_SIZE PMC passes of
-tools/pmc_passes.sh, corrected as MI355X_MICROARCH.md §HBM prescribes for gfx950: FETCH_SIZE counts
-128-B read requests at 64 B, so read bytes = 2 x FETCH_SIZE (calibrated on this workload's own access
-pattern: unfused depth-0 k_intersect reads 24 B/ray exactly → ratio 1.985); WRITE_SIZE is exact.
-Units are KiB per dispatch.  Writes profiles/dominant_kernel_traffic.json.
-usage: tools/pmc_traffic.py PMC_DIR KERNEL_SUBSTR [steady_depths_only]"""
+"""Per-mode figures of the dominant kernel from the PMC passes of tools/pmc_passes.sh, written to
+profiles/dominant_kernel_traffic.json[MODE] for bench.py (roofline.traffic, roofline_valu):
+  hbm_bytes_per_ray   (2 x FETCH_SIZE + WRITE_SIZE) / rays per launch.  Corrected as MI355X_MICROARCH.md §HBM prescribes for
+                      gfx950: FETCH_SIZE counts 128-B read requests at 64 B (calibrated on this workload: unfused depth-0
+                      k_intersect reads exactly 24 B/ray -> ratio 1.985); WRITE_SIZE is exact.  Units: KiB per dispatch.
+  valu_per_group      SQ_INSTS_VALU / 64-ray groups per launch (salu_per_group likewise)
+  valu_busy_frac      SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (SIMDs x kernel cycles), kernel cycles =
+                      SQ_BUSY_CYCLES / shader engines
+  shader_clock_ghz    kernel cycles / kernel duration from the kernel trace of the same pass
+The rays per launch come from the bench line the first pass printed (pass1.json).
+usage: tools/pmc_traffic.py PMC_DIR KERNEL_SUBSTR MODE"""
 import csv, glob, json, os, sys
-d, kern = sys.argv[1], sys.argv[2]
-vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+d, kern, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+vals = {}
+dur = []
 for f in sorted(glob.glob(os.path.join(d, "pass*", "p_counter_collection.csv"))):
     per = {}
     for r in csv.DictReader(open(f)):
-        if kern in r["Kernel_Name"] and r["Counter_Name"] in vals:
-            per.setdefault(int(r["Dispatch_Id"]), 0.0)
-            per[int(r["Dispatch_Id"])] += float(r["Counter_Value"])
-            name = r["Counter_Name"]
-    if per:
-        vals[name] += list(per.values())
-n = min(len(vals["FETCH_SIZE"]), len(vals["WRITE_SIZE"]))
-fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024
-write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024
-out = {"kernel": kern, "dispatches": n, "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write),
-       "hbm_bytes_per_launch": round(2 * fetch + write),
-       "note": "2 x FETCH_SIZE + WRITE_SIZE, averaged over all dispatches of the kernel in the PMC run (same bench "
-               "configuration as the timed run); gfx950 FETCH_SIZE counts 128-B requests as 64 B"}
+        if kern in r["Kernel_Name"]:
+            per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
+            per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
+    for c, v in per.items():
+        vals.setdefault(c, []).extend(v.values())
+    kt = os.path.join(os.path.dirname(f), "p_kernel_trace.csv")
+    if os.path.exists(kt) and "SQ_BUSY_CYCLES" in per:
+        for r in csv.DictReader(open(kt)):
+            if kern in r["Kernel_Name"]:
+                dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+mean = {c: sum(v) / len(v) for c, v in vals.items()}
+line = json.loads(open(os.path.join(d, "pass1.json")).read().strip().split("\n")[-1])
+rays = line["roofline"]["rays_per_launch"] if line.get("roofline") else None
+if rays is None:  # passes run with --no-kernel-events: derive from the statistics in config
+    raise SystemExit("pass1.json has no roofline object; run the passes with kernel events enabled")
+cus = line["config"]["cus"]
+fetch, write = mean["FETCH_SIZE"] * 1024, mean["WRITE_SIZE"] * 1024
+cycles = mean["SQ_BUSY_CYCLES"] / 32.0  # 32 shader engines report
+out = {"kernel": kern, "dispatches": len(vals["FETCH_SIZE"]), "rays_per_launch": rays,
+       "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write),
+       "hbm_bytes_per_launch": round(2 * fetch + write), "hbm_bytes_per_ray": round((2 * fetch + write) / rays, 2),
+       "algorithmic_bytes_per_ray": round(line["roofline"]["algorithmic_bytes_per_launch"] / rays, 2),
+       "valu_per_group": round(mean["SQ_INSTS_VALU"] / (rays / 64), 1), "salu_per_group": round(mean["SQ_INSTS_SALU"] / (rays / 64), 1),
+       "lds_per_group": round(mean["SQ_INSTS_LDS"] / (rays / 64), 1),
+       "valu_busy_frac": round(mean["SQ_ACTIVE_INST_VALU"] * 4 / (cus * 4 * cycles), 4),
+       "wave_wait_frac": round(mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"], 4),
+       "wave_issue_stall_frac": round(mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"], 4),
+       "shader_clock_ghz": round(cycles / (sum(dur) / len(dur)), 3) if dur else None,
+       "avg_launch_us_under_pmc": round(sum(dur) / len(dur) / 1e3, 1) if dur else None,
+       "note": "PMC passes of `bench.py --arith %s` (tools/pmc_passes.sh); per-ray figures are scaled by a run's own rays per launch in bench.py" % mode}
 print(json.dumps(out, indent=1))
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-json.dump(out, open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json"), "w"), indent=1)
+path = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+try:
+    allm = json.load(open(path))
+    if "kernel" in allm:  # round-1 layout
+        allm = {}
+except Exception:
+    allm = {}
+allm[mode] = out
+json.dump(allm, open(path, "w"), indent=1)
