@@ -104,6 +104,7 @@ def lib() -> C.CDLL:
     L.pt_stage_shade.argtypes = [C.c_int, C.c_int, _ip, _ip, _fp, _fp, _ip, _fp, _fp, _fp, _fp, _ip]
     _u8p = C.POINTER(C.c_uint8)
     L.pt_save_u8.argtypes = [C.c_float, _u8p]
+    L.pt_stage_save_u8.argtypes = [C.c_int, C.c_int, C.c_float, _fp, _u8p]
     L.pt_ctx_create.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), C.POINTER(C.c_void_p)]
     L.pt_ctx_destroy.argtypes = [C.c_void_p]
     L.pt_ctx_render.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -296,6 +297,13 @@ class Renderer:
         pt = np.zeros((3, n), np.float32)
         _check(lib().pt_stage_intersect(n, _f(o), _f(d), _f(t), _f(nrm), _i(mat), _f(pt)))
         return dict(t=t, nrm=nrm, mat=mat, pt=pt)
+
+    @staticmethod
+    def stage_save_u8(rgb_sum: np.ndarray, w: int, h: int, samples: float) -> np.ndarray:
+        a = np.ascontiguousarray(rgb_sum, np.float32)
+        out = np.empty((h, w, 3), np.uint8)
+        _check(lib().pt_stage_save_u8(w, h, C.c_float(samples), _f(a), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
 
     @staticmethod
     def stage_shade(depth: int, it, pixel, hit: dict, o, d, color):

@@ -897,4 +897,22 @@ int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, 
   return 0;
 }
 
+// k_save_u8 on a caller-supplied SUM image of whole rows (tests: pins the device conversion to the reference writer's bytes)
+int pt_stage_save_u8(int w, int h, float samples, const float* rgb_sum, uint8_t* rgb8) {
+  if (need(g_default, "pt_stage_save_u8")) return -1;
+  Ctx& g = *g_default;
+  if (w <= 0 || h <= 0 || h >= 32768 || !rgb_sum || !rgb8 || !(samples > 0.0f)) return fail("pt_stage_save_u8: bad argument");
+  HIP_OK(hipSetDevice(g.device));
+  Scratch sc;
+  const size_t n = (size_t)w * h;
+  float* d_img = sc.get<float>(3 * n);
+  uint8_t* d_u8 = sc.get<uint8_t>(3 * n);
+  if (!d_img || !d_u8) return fail("pt_stage_save_u8: out of device memory");
+  HIP_OK(hipMemcpy(d_img, rgb_sum, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+  g.k->save_u8(g.stream, (int)n, w, samples, d_img, d_u8);
+  HIP_OK(hipStreamSynchronize(g.stream));
+  HIP_OK(hipMemcpy(rgb8, d_u8, 3 * n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 }  // extern "C"

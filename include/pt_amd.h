@@ -237,6 +237,9 @@ int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, 
                    const int32_t* material, const float* point, float* origin, float* dir, float* color,
                    int32_t* alive);
 
+/* saveImage + savePNG conversion kernel (pt_save_u8) on a caller-supplied SUM image of w*h pixels (tests). */
+int pt_stage_save_u8(int w, int h, float samples, const float* rgb_sum, uint8_t* rgb8);
+
 /* ---- image output (src/image.cpp:22-45, src/main.cpp:86-107) ------------- */
 /* rgb_sum: W*H*3 floats (raw orientation); writes <path> as 8-bit PNG of
  * clamp(sum/samples)*255 with the x mirror of saveImage(); no gamma. */

@@ -95,6 +95,23 @@ def test_save_u8_on_device_equals_host_png_writer(scene_dir, tmp_path):
         r.free()
 
 
+def test_device_conversion_matches_reference_compiled_writer(scene_dir):
+    """k_save_u8 against tests/golden/ref_image.json (the reference's own writer compiled in place): same bytes for
+    negatives, exact 1, byte boundaries, > 1, infinities and NaN, in every arithmetic mode's build of the kernel."""
+    import json
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_image.json")))
+    w, h = g["width"], g["height"]
+    img = np.array(g["sum_bits"], np.uint32).view(np.float32).reshape(h * w, 3)
+    want = np.array(g["png_rgb8"], np.uint8).reshape(h, w, 3)
+    for arith in ("exact", "fma", "fast"):
+        r = capi.Renderer(capi.Scene(scene_dir["cornell"], res=(16, 16)), arith=arith)
+        try:
+            assert np.array_equal(capi.Renderer.stage_save_u8(img, w, h, float(g["samples"])), want), arith
+        finally:
+            r.free()
+
+
 def test_pt_render_gpus_matches_shim_path(scene_dir, tmp_path):
     """`pt_render --gpus 1` (pt_group + RCCL communicator + device-side PNG bytes) against the default path
     (pathtrace.h shim + host PNG writer): identical PNG and PFM files; with every visible device too."""

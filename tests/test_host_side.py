@@ -116,6 +116,26 @@ def test_png_writer_matches_saveimage_semantics(tmp_path):
     assert np.array_equal(body.view(np.uint32), avg.view(np.uint32))
 
 
+def test_png_writer_matches_reference_compiled_writer(tmp_path):
+    """tests/golden/ref_image.json holds what the REFERENCE's image writer (src/image.cpp + src/stb.cpp compiled in place,
+    oracle/ref_image_harness.cpp, filled like saveImage() main.cpp:91-97) put into its PNG for an image with negatives,
+    zeros, exactly 1, values around byte boundaries, > 1, infinities and a NaN: pt_save_png must write the same pixels."""
+    g = json.load(open(os.path.join(HERE, "golden", "ref_image.json")))
+    w, h = g["width"], g["height"]
+    img = np.array(g["sum_bits"], np.uint32).view(np.float32).reshape(h * w, 3)
+    p = str(tmp_path / "g.png")
+    capi.save_png(p, img, w, h, float(g["samples"]))
+    assert np.array_equal(_decode_png(p), np.array(g["png_rgb8"], np.uint8).reshape(h, w, 3))
+
+
+def test_output_basename_is_the_reference_file_name():
+    """main.cpp:99-102: <FILE>.<UTC start time %Y-%m-%d_%H-%M-%Sz>.<samples as streamed float>samp; one start time per process."""
+    a = capi.output_basename("cornell", 5000)
+    assert re.fullmatch(r"cornell\.\d{4}-\d\d-\d\d_\d\d-\d\d-\d\dz\.5000samp", a), a
+    b = capi.output_basename("x", 1000000)
+    assert b.endswith(".1e+06samp") and b.split(".")[1] == a.split(".")[1]
+
+
 def test_no_cpu_fallback_without_gpu(scene_dir):
     import torch
     if torch.cuda.is_available():

@@ -1,15 +1,13 @@
 #!/bin/bash
-# Two PMC passes (instruction mix, TA/TCP activity) of one run_config configuration for several builds of the library.
-# usage: tools/pmc_libs.sh OUTDIR "run_config args" build/libA.so build/libB.so ...
+# Two PMC passes (instruction mix, TA/TCP activity) of one run_config configuration for several builds of the library,
+# loaded through PT_AMD_LIB (the in-tree product library is never overwritten; "-" = the in-tree library).
+# usage: tools/pmc_libs.sh OUTDIR "run_config args" build/variants/A.so build/variants/B.so ...
 set -u
 OUT=$1; ARGS=$2; shift; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-DST=$R/cosc_4397_pathtracing_raytracing_project_amd/libpt_amd.so
-cp $DST /tmp/orig.so
 for lib in "$@"; do
-  n=$(basename $lib .so)
-  cp $lib $DST
+  if [ "$lib" = "-" ]; then unset PT_AMD_LIB; n=intree; else export PT_AMD_LIB=$(readlink -f $lib); n=$(basename $lib .so); fi
   mkdir -p "$R/$OUT/$n"
   i=0
   for grp in \
@@ -18,5 +16,5 @@ for lib in "$@"; do
     i=$((i+1))
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$R/$OUT/$n/pass$i" -o p -- python3 "$R/tools/run_config.py" $ARGS > "$R/$OUT/$n/pass$i.log" 2> "$R/$OUT/$n/pass$i.err" || echo "pass $i failed"
   done
+  rm -f "$R/$OUT/$n"/pass*/*.db
 done
-cp /tmp/orig.so $DST
