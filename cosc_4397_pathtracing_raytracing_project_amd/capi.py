@@ -53,7 +53,7 @@ class PtOptions(C.Structure):
     _fields_ = [("device", C.c_int32), ("pixel_begin", C.c_int32), ("pixel_count", C.c_int32),
                 ("iters_per_batch", C.c_int32), ("num_queues", C.c_int32), ("blocks_per_cu", C.c_int32),
                 ("time_kernels", C.c_int32), ("legacy_traversal", C.c_int32), ("debug_flags", C.c_int32), ("unfused_primary", C.c_int32), ("unfused_bounces", C.c_int32), ("stripe_pixels", C.c_int32), ("stripe_stride", C.c_int32),
-                ("arith", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("arith", C.c_int32), ("aa_jitter", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class PtStats(C.Structure):
@@ -206,7 +206,7 @@ def build_transform(trs: Sequence[float]):
 def make_options(device: int = 0, pixel_begin: int = 0, pixel_count: int = 0, iters_per_batch: int = 0,
                  num_queues: int = 0, blocks_per_cu: int = 0, time_kernels: bool = False, legacy_traversal: bool = False,
                  debug_flags: int = 0, unfused_primary: bool = False, unfused_bounces: bool = False,
-                 stripe_pixels: int = 0, stripe_stride: int = 0, arith="exact") -> PtOptions:
+                 stripe_pixels: int = 0, stripe_stride: int = 0, arith="exact", aa_jitter: bool = False) -> PtOptions:
     opt = PtOptions()
     opt.device = device
     opt.pixel_begin = pixel_begin
@@ -222,6 +222,7 @@ def make_options(device: int = 0, pixel_begin: int = 0, pixel_count: int = 0, it
     opt.stripe_pixels = int(stripe_pixels)
     opt.stripe_stride = int(stripe_stride)
     opt.arith = ARITH[arith] if isinstance(arith, str) else int(arith)
+    opt.aa_jitter = 1 if aa_jitter else 0
     return opt
 
 

@@ -14,6 +14,7 @@ GuiDataContainer* guiData = nullptr;
 int q_first = 0, q_count = 0;  // queued, not yet submitted iterations [q_first, q_first+q_count)
 int last_iter = 0;
 int arith_mode = PT_ARITH_EXACT;
+int aa_mode = 0;
 
 void check(int rc, const char* what) {  // pathtrace.cu:141-150
   if (rc == 0) return;
@@ -28,12 +29,14 @@ void flush() {
 
 void InitDataContainer(GuiDataContainer* imGuiData) { guiData = imGuiData; }
 void pathtraceSetArith(int pt_arith) { arith_mode = pt_arith; }
+void pathtraceSetAntialias(int on) { aa_mode = on ? 1 : 0; }
 
 void pathtraceInit(pt::Scene* scene) {
   hst_scene = scene;
   PtSceneDesc d = scene->desc();
   PtOptions opt{};
   opt.arith = arith_mode;
+  opt.aa_jitter = aa_mode;
   check(pt_init(&d, &opt), "pathtraceInit");
   q_count = 0;
   last_iter = 0;

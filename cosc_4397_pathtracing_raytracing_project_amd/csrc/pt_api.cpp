@@ -92,6 +92,7 @@ struct PtContext {
   bool legacy = false;
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
+  bool aa_jitter = false;
   int grid_primary = 0, grid_bounce = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
@@ -311,6 +312,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   b.N = g.N;
   b.pixel_begin = g.pixel_begin;
   b.trace_depth = g.depth;
+  b.aa_jitter = g.aa_jitter ? 1 : 0;
   b.debug = kAblateBuild ? g.debug_flags : 0;
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;
@@ -498,6 +500,7 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
     g.cull_margin = 1e-3f * max_xf + 1e-4f * extent;
   }
   g.legacy = opt.legacy_traversal != 0;
+  g.aa_jitter = opt.aa_jitter != 0;
   g.debug_flags = opt.debug_flags;
   g.fuse_primary = !g.legacy && !opt.unfused_primary;
   g.fuse_bounces = g.fuse_primary && !opt.unfused_bounces;
@@ -803,6 +806,7 @@ int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
   if (!pb.o || !pb.d || !pb.c || !pb.slot || !cnt) return fail("pt_stage_generate: out of device memory");
   ptk::BatchInfo b{};
   b.iter_first = 1, b.K = 1, b.N = n, b.pixel_begin = pix_begin, b.trace_depth = g.depth;
+  b.aa_jitter = g.aa_jitter ? 1 : 0;
   g.k->generate(g.stream, g.grid, g.dcam, b, qs, pb, cnt);
   HIP_OK(hipStreamSynchronize(g.stream));
   for (int c = 0; c < 3; ++c) {

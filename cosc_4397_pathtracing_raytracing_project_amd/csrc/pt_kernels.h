@@ -50,6 +50,7 @@ struct BatchInfo {
   int32_t stripe, gap;
   float inv_stripe;
   int32_t trace_depth;
+  int32_t aa_jitter;  // 1: stochastic anti-aliasing of the camera rays (extension, PtOptions.aa_jitter)
   int32_t debug;  // profiling ablations (wrong results; honoured only by -DPT_ABLATE builds): 4 = skip primitive tests,
                   // 8 = skip shade_bounce
 };

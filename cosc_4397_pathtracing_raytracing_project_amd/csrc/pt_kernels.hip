@@ -186,8 +186,8 @@ struct Ar {
     if constexpr (EX) return ex::geom_test<TYPE, QO>(G, ro, rd, point, normal, qo_pre);
     else return md::geom_test<TYPE, QO>(G, ro, rd, point, normal, qo_pre);
   }
-  static PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p) {
-    if constexpr (EX) return ex::camera_dir(cam, inv_w, p); else return md::camera_dir(cam, inv_w, p);
+  static PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p, bool aa, float jx, float jy) {
+    if constexpr (EX) return ex::camera_dir(cam, inv_w, p, aa, jx, jy); else return md::camera_dir(cam, inv_w, p, aa, jx, jy);
   }
   static PT_DEV f3 xf_point(const float* m, f3 v) { if constexpr (EX) return ex::mulMV<1>(m, v); else return md::mulMV<1>(m, v); }
 };
@@ -243,6 +243,14 @@ PT_DEV uint32_t iter_hash_of(const uint32_t* tab, const SceneTables& sc, const B
   return iter_hash_entries(sc) > 0 ? tab[k] : iter_hash(b.iter_first + k, depth);
 }
 
+// Anti-aliasing jitter of sample (iteration, global pixel): two draws of an engine seeded in a hash domain of its own
+// ("depth" field 0x100: bit 30, which no path depth < 64 produces), so the streams of the reference semantics are untouched.
+PT_DEV void aa_jitter(int iter, int pixel, float& jx, float& jy) {
+  MinStd rng(utilhash((1u << 31) | (1u << 30) | (uint32_t)iter) ^ utilhash((uint32_t)pixel));
+  jx = rng.u01() - 0.5f;
+  jy = rng.u01() - 0.5f;
+}
+
 // ───────────────────────────── LDS staging ─────────────────────────────────
 // Copies `bytes` (multiple of 16) from global to LDS with 16-B accesses.
 PT_DEV void stage16(void* lds, const void* g, int bytes) {
@@ -284,7 +292,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
       int k, pl;
       divmod((int)gid, b.N, inv_n, k, pl);
       const int p = global_pixel(b, pl);  // global pixel index
-      const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p);
+      float jx = 0.f, jy = 0.f;
+      if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
+      const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
       const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
       out.o[at] = cam.pos[0], out.o[S + at] = cam.pos[1], out.o[2 * S + at] = cam.pos[2];
       out.d[at] = d.x, out.d[S + at] = d.y, out.d[2 * S + at] = d.z;
@@ -1275,7 +1285,9 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     int k, pl;
     divmod(slot, b.N, inv_n, k, pl);
     const int p = global_pixel(b, pl);  // global pixel index
-    const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p);
+    float jx = 0.f, jy = 0.f;
+    if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
+    const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
     // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
     // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.

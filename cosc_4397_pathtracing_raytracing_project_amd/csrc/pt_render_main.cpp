@@ -4,7 +4,7 @@
 // the reference takes resolution, iteration count and depth from the scene file (scene.cpp:103-114).
 //
 //   pt_render SCENE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm]
-//                       [--arith exact|fma|fast] [--gpus K] [--stamp]
+//                       [--arith exact|fma|fast] [--gpus K] [--stamp] [--aa]
 //
 // Without --gpus the run goes through the pathtrace.h-compatible shim (pathtraceInit / pathtrace per
 // iteration / pathtraceFree), i.e. the code path a reference main.cpp would take.  With --gpus K (K >= 1;
@@ -27,11 +27,11 @@
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::printf("Usage: %s SCENEFILE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] "
-                "[--arith exact|fma|fast] [--gpus K] [--stamp]\n", argv[0]);
+                "[--arith exact|fma|fast] [--gpus K] [--stamp] [--aa]\n", argv[0]);
     return 1;
   }
   int rw = 0, rh = 0, spp = 0, depth = 0, gpus = -1, arith = PT_ARITH_EXACT;
-  bool pfm = false, stamp = false;
+  bool pfm = false, stamp = false, aa = false;
   std::string out;
   for (int i = 2; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--res") && i + 1 < argc) std::sscanf(argv[++i], "%dx%d", &rw, &rh);
@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--pfm")) pfm = true;
     else if (!std::strcmp(argv[i], "--stamp")) stamp = true;
+    else if (!std::strcmp(argv[i], "--aa")) aa = true;  // extension: stochastic anti-aliasing (PtOptions.aa_jitter)
     else if (!std::strcmp(argv[i], "--arith") && i + 1 < argc) {
       const char* a = argv[++i];
       if (!std::strcmp(a, "exact")) arith = PT_ARITH_EXACT;
@@ -83,6 +84,7 @@ int main(int argc, char** argv) {
     InitDataContainer(&gui);
     pathtraceFree();  // main.cpp:134 frees before the first init
     pathtraceSetArith(arith);
+    pathtraceSetAntialias(aa);
     pathtraceInit(scene);
     const auto t0 = std::chrono::high_resolution_clock::now();
     for (int it = 1; it <= iters; ++it) pathtrace(nullptr, 0, it);  // main.cpp:138-149
@@ -110,6 +112,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < gpus; ++i) devices[i] = i;
     PtOptions opt{};
     opt.arith = arith;
+    opt.aa_jitter = aa ? 1 : 0;
     const PtSceneDesc desc = scene->desc();
     PtGroup* grp = nullptr;
     if (pt_group_create(&desc, &opt, devices.data(), gpus, &grp)) {

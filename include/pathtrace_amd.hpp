@@ -41,3 +41,5 @@ void pathtrace(pt_uchar4* pbo, int frame, int iteration);
 void pathtraceSyncImage();
 // extension: arithmetic mode (PT_ARITH_*, pt_amd.h) of the next pathtraceInit; default PT_ARITH_EXACT
 void pathtraceSetArith(int pt_arith);
+// extension: stochastic anti-aliasing (PtOptions.aa_jitter) of the next pathtraceInit; default off = reference semantics
+void pathtraceSetAntialias(int on);

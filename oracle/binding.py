@@ -73,6 +73,8 @@ def lib() -> C.CDLL:
         L.orc_geom_test.argtypes = [C.c_int, fp, fp, fp, fp, ip]
         L.orc_geom_test.restype = C.c_float
         L.orc_generate.argtypes = [C.c_int, C.c_int, fp, fp]
+        L.orc_generate_iter.argtypes = [C.c_int, C.c_int, C.c_int, fp, fp]
+        L.orc_set_aa_jitter.argtypes = [C.c_int]
         L.orc_intersect.argtypes = [C.c_int, fp, fp, fp, fp, ip, fp, ip, ip, C.POINTER(C.c_long)]
         L.orc_shade.argtypes = [C.c_int, C.c_int, ip, ip, fp, fp, ip, fp, fp, fp, fp, ip]
         L.orc_render.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp,
@@ -142,10 +144,15 @@ def resolution():
     return c.res[0], c.res[1]
 
 
-def generate(pix_begin: int, count: int):
+def set_aa_jitter(on: bool) -> None:
+    """Extension (not in the reference): stochastic anti-aliasing of the camera rays; off = reference semantics."""
+    lib().orc_set_aa_jitter(1 if on else 0)
+
+
+def generate(pix_begin: int, count: int, iteration: int = 1):
     o = np.zeros((3, count), np.float32)
     d = np.zeros((3, count), np.float32)
-    lib().orc_generate(pix_begin, count, _fp(o), _fp(d))
+    lib().orc_generate_iter(int(iteration), pix_begin, count, _fp(o), _fp(d))
     return o, d
 
 
