@@ -141,3 +141,23 @@ def test_pt_render_stamp_uses_reference_file_name(scene_dir, tmp_path):
     names = os.listdir(tmp_path)
     # <FILE>.<UTC start time>.<samples>samp.png (main.cpp:99-102, preview.cpp:18-24)
     assert any(re.fullmatch(r"cornell\.\d{4}-\d\d-\d\d_\d\d-\d\d-\d\dz\.2samp\.png", n) for n in names), names
+
+
+def test_bench_two_ranks_rehearsal_on_one_card(tmp_path):
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with two
+    ranks sharing the one card of the test box: RCCL needs one GPU per rank, so the tile gather goes through gloo
+    (PT_DIST_BACKEND); everything else — striped tiles with global pixel indices, per-rank renderers, barrier, max-over-ranks
+    timing, one JSON line from rank 0 — is the code path of the real run."""
+    import json
+    import sys
+    env = dict(os.environ, PT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "interleaved-row tiles" in d["config"]["workload"] and d["config"]["arith"] == "fast"
+    assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
