@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
     L.pt_group_sync.argtypes = [C.c_void_p]
     L.pt_group_gather.argtypes = [C.c_void_p, _fp]
     L.pt_group_gather_u8.argtypes = [C.c_void_p, C.c_float, _u8p]
+    L.pt_group_preview_rgba8.argtypes = [C.c_void_p, C.c_int, _u8p]
     L.pt_write_png_rgb8.argtypes = [C.c_char_p, _u8p, C.c_int, C.c_int]
     L.pt_output_basename.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.pt_save_png.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
@@ -344,6 +345,13 @@ class Group:
         w, h = self.scene.resolution
         out = np.empty((h, w, 3), np.uint8)
         _check(lib().pt_group_gather_u8(self._h, C.c_float(samples), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def preview(self, iterations: int) -> np.ndarray:
+        """Progressive preview of the running average (sendImageToPBO on every device + one exchange): uint8 [H*W, 4]."""
+        w, h = self.scene.resolution
+        out = np.empty((w * h, 4), np.uint8)
+        _check(lib().pt_group_preview_rgba8(self._h, int(iterations), out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
     def stats(self, i: int = 0) -> PtStats:

@@ -40,8 +40,9 @@ struct PtGroup {
   size_t recv_pixels = 0;
   float* d_recv = nullptr;    // root: tiles of devices 1..n-1, float RGB
   float* d_full = nullptr;    // root: assembled frame
-  uint8_t* d_recv8 = nullptr; // same for the converted bytes
+  uint8_t* d_recv8 = nullptr; // same for the converted bytes (3 B/pixel)
   uint8_t* d_full8 = nullptr;
+  std::vector<uint8_t*> d_prev;  // per device: RGBA8 preview of its tile (sendImageToPBO)
 };
 
 namespace {
@@ -56,6 +57,11 @@ void release(PtGroup* g) {
   if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
   for (void* p : {(void*)g->d_recv, (void*)g->d_full, (void*)g->d_recv8, (void*)g->d_full8})
     if (p) (void)hipFree(p);
+  for (size_t i = 0; i < g->d_prev.size(); ++i)
+    if (g->d_prev[i]) {
+      (void)hipSetDevice(g->devices[i]);
+      (void)hipFree(g->d_prev[i]);
+    }
   for (PtContext* c : g->ctx) (void)pt_ctx_destroy(c);
   delete g;
 }
@@ -190,6 +196,41 @@ int pt_group_gather_u8(PtGroup* g, float samples, uint8_t* rgb8_host) {
     if (place_rows(g, i, i == 0 ? tiles[0] : g->d_recv8 + 3 * g->recv_off[i], g->d_full8, 3)) return -1;
   HIP_OK(hipMemcpyAsync(rgb8_host, g->d_full8, frame * 3, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])));
   return pt_group_sync(g);
+}
+
+// Progressive preview (the reference converts and shows the running average after EVERY iteration: sendImageToPBO,
+// src/pathtrace.cu:250-268,618): every device converts its own rows (average over `iterations`, gamma 1/2.2, clamp,
+// RGBA8), then the same single exchange + row placement as the write-out, 4 B per pixel.  Meant to be called every N
+// batches while rendering continues; it synchronises the devices (the image is read at a batch boundary).
+int pt_group_preview_rgba8(PtGroup* g, int iterations, uint8_t* rgba_host) {
+  if (!g || !rgba_host || iterations <= 0) return pt_fail("pt_group_preview_rgba8: bad argument");
+  const size_t frame = (size_t)g->W * g->H;
+  if (g->d_prev.empty()) g->d_prev.assign(g->n, nullptr);
+  for (int i = 0; i < g->n; ++i) {
+    HIP_OK(hipSetDevice(g->devices[i]));
+    if (!g->d_prev[i]) HIP_OK(hipMalloc((void**)&g->d_prev[i], (size_t)pt_ctx_pixel_count(g->ctx[i]) * 4));
+    if (pt_ctx_preview_rgba8_device(g->ctx[i], iterations, g->d_prev[i])) return -1;
+  }
+  HIP_OK(hipSetDevice(g->devices[0]));
+  if (g->n == 1) {
+    HIP_OK(hipMemcpyAsync(rgba_host, g->d_prev[0], frame * 4, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])));
+    return pt_group_sync(g);
+  }
+  uint8_t *full = nullptr, *recv = nullptr;  // previews are occasional: scratch buffers, freed below
+  HIP_OK(hipMalloc((void**)&full, frame * 4));
+  HIP_OK(hipMalloc((void**)&recv, g->recv_pixels * 4));
+  int rc = exchange(g, ncclUint8, 4, recv, [&](int i) { return (const uint8_t*)g->d_prev[i]; });
+  if (!rc) {
+    (void)hipSetDevice(g->devices[0]);
+    for (int i = 0; i < g->n && !rc; ++i) rc = place_rows(g, i, i == 0 ? (const uint8_t*)g->d_prev[0] : recv + 4 * g->recv_off[i], full, 4);
+  }
+  if (!rc && hipMemcpyAsync(rgba_host, full, frame * 4, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])) != hipSuccess)
+    rc = pt_fail("pt_group_preview_rgba8: copy failed");
+  if (!rc) rc = pt_group_sync(g);
+  (void)hipSetDevice(g->devices[0]);
+  (void)hipFree(full);
+  (void)hipFree(recv);
+  return rc;
 }
 
 }  // extern "C"

@@ -4,16 +4,19 @@
 // the reference takes resolution, iteration count and depth from the scene file (scene.cpp:103-114).
 //
 //   pt_render SCENE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm]
-//                       [--arith exact|fma|fast] [--gpus K] [--stamp] [--aa]
+//                       [--arith exact|fma|fast] [--gpus K] [--stamp] [--aa] [--preview N]
 //
 // Without --gpus the run goes through the pathtrace.h-compatible shim (pathtraceInit / pathtrace per
 // iteration / pathtraceFree), i.e. the code path a reference main.cpp would take.  With --gpus K (K >= 1;
 // K = 0: all visible devices) it goes through pt_group_*: K devices in this one process, row-interleaved
 // tiles, one grouped RCCL send/recv at write-out (BASELINE config 4), PNG bytes converted on the devices.
+// --preview N (with --gpus): every N iterations the running average is converted on the devices and gathered
+// (pt_group_preview_rgba8 — the reference shows it after every iteration, pathtrace.cu:618) into PREFIX.preview.png.
 // Output name: PREFIX.<spp>samp.png, or with --stamp the reference's own
 // <FILE>.<UTC start time>.<spp>samp.png (main.cpp:99-102).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -27,10 +30,10 @@
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::printf("Usage: %s SCENEFILE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] "
-                "[--arith exact|fma|fast] [--gpus K] [--stamp] [--aa]\n", argv[0]);
+                "[--arith exact|fma|fast] [--gpus K] [--stamp] [--aa] [--preview N]\n", argv[0]);
     return 1;
   }
-  int rw = 0, rh = 0, spp = 0, depth = 0, gpus = -1, arith = PT_ARITH_EXACT;
+  int rw = 0, rh = 0, spp = 0, depth = 0, gpus = -1, arith = PT_ARITH_EXACT, preview = 0;
   bool pfm = false, stamp = false, aa = false;
   std::string out;
   for (int i = 2; i < argc; ++i) {
@@ -39,6 +42,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--depth") && i + 1 < argc) depth = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
     else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--preview") && i + 1 < argc) preview = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--pfm")) pfm = true;
     else if (!std::strcmp(argv[i], "--stamp")) stamp = true;
     else if (!std::strcmp(argv[i], "--aa")) aa = true;  // extension: stochastic anti-aliasing (PtOptions.aa_jitter)
@@ -121,7 +125,21 @@ int main(int argc, char** argv) {
     }
     std::vector<uint8_t> rgb8((size_t)W * H * 3);
     const auto t0 = std::chrono::high_resolution_clock::now();
-    int rc = pt_group_render(grp, 1, iters);
+    int rc = 0;
+    if (preview > 0) {
+      std::vector<uint8_t> rgba((size_t)W * H * 4), rgb((size_t)W * H * 3);
+      for (int it = 1; it <= iters && !rc; it += preview) {
+        const int n = std::min(preview, iters - it + 1);
+        rc = pt_group_render(grp, it, n);
+        if (!rc && it + n <= iters) {  // progressive preview of what has been accumulated so far
+          rc = pt_group_preview_rgba8(grp, it + n - 1, rgba.data());
+          for (size_t p = 0; p < (size_t)W * H; ++p) rgb[3 * p] = rgba[4 * p], rgb[3 * p + 1] = rgba[4 * p + 1], rgb[3 * p + 2] = rgba[4 * p + 2];
+          if (!rc) pt_write_png_rgb8((out + ".preview.png").c_str(), rgb.data(), W, H);
+        }
+      }
+    } else {
+      rc = pt_group_render(grp, 1, iters);
+    }
     if (!rc) rc = pt_group_gather_u8(grp, (float)iters, rgb8.data());  // the write-out gather: 3 B per pixel
     secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     if (rc) {

@@ -227,6 +227,9 @@ int pt_group_render(PtGroup* g, int iter_first, int iter_count); /* asynchronous
 int pt_group_sync(PtGroup* g);
 int pt_group_gather(PtGroup* g, float* rgb_sum_host);             /* W*H*3 floats, raw orientation */
 int pt_group_gather_u8(PtGroup* g, float samples, uint8_t* rgb8_host); /* W*H*3 bytes as pt_save_u8, converted on each device */
+/* Progressive preview of the running average (sendImageToPBO, pathtrace.cu:250-268, which the reference runs after every
+ * iteration): W*H RGBA8 bytes, raw orientation, converted on each device, one exchange of 4 B per pixel. */
+int pt_group_preview_rgba8(PtGroup* g, int iterations, uint8_t* rgba_host);
 
 /* ---- stage-level entry points (same kernels, caller-supplied HOST arrays, SoA:
  * vec3 arrays are [3][n]).  Used by the parity tests; each uploads, launches the
