@@ -93,6 +93,7 @@ struct PtContext {
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
   bool aa_jitter = false;
+  bool has_triangles = false;  // SceneTables::has_triangles
   int grid_primary = 0, grid_bounce = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
@@ -278,6 +279,7 @@ ptk::SceneTables tables(const Ctx& g) {
   t.top_xor = (g.debug_flags & 32) ? 0ull : g.top_xor;
   t.lds_table_bytes = g.lds_table_bytes;
   t.max_batch_iters = g.K;
+  t.has_triangles = g.has_triangles ? 1 : 0;
   return t;
 }
 
@@ -490,6 +492,7 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
     // to world space + rounding of the transforms at the scene's coordinate magnitudes)
     float max_xf = 1.0f, extent = 1.0f;
     for (const PtGeom& gm : g.geoms) {
+      if (gm.type == PT_GEOM_TRIANGLE) continue;  // world-space test: the pull-back is 1e-4 world units (max_xf >= 1 covers it)
       float f = 0.f;
       for (int c = 0; c < 3; ++c)
         for (int r = 0; r < 3; ++r) f += gm.transform[c * 4 + r] * gm.transform[c * 4 + r];
@@ -507,11 +510,16 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   std::vector<ptd::Geom> dg(g.geoms.size());
   for (size_t i = 0; i < g.geoms.size(); ++i) {
     std::memset(&dg[i], 0, sizeof(ptd::Geom));
+    dg[i].type = g.geoms[i].type;
+    dg[i].material = g.geoms[i].materialid;
+    if (g.geoms[i].type == PT_GEOM_TRIANGLE) {  // mesh extension: the three world-space vertices where `inv` would be
+      std::memcpy(dg[i].inv, g.geoms[i].transform, 9 * sizeof(float));
+      g.has_triangles = true;
+      continue;
+    }
     pack_rows(g.geoms[i].inverseTransform, dg[i].inv);
     pack_rows(g.geoms[i].transform, dg[i].xf);
     pack_rows(g.geoms[i].invTranspose, dg[i].invT);
-    dg[i].type = g.geoms[i].type;
-    dg[i].material = g.geoms[i].materialid;
     box_normal_table(dg[i].invT, dg[i].box_normal);
   }
   std::vector<ptd::Mat> dm(g.mats.size());
@@ -619,9 +627,12 @@ int pt_ctx_create(const PtSceneDesc* sc, const PtOptions* opt_in, PtContext** ou
   if (sc->trace_depth <= 0 || sc->trace_depth > PT_MAX_DEPTH) return fail("pt_init: trace_depth %d out of range", sc->trace_depth);
   const int W = sc->camera.resolution[0], H = sc->camera.resolution[1];
   if (W <= 0 || H <= 0 || (int64_t)W * H > (1ll << 30)) return fail("pt_init: bad resolution %dx%d", W, H);
-  for (int i = 0; i < sc->num_geoms; ++i)
+  for (int i = 0; i < sc->num_geoms; ++i) {
     if (sc->geoms[i].materialid < 0 || sc->geoms[i].materialid >= sc->num_materials)
       return fail("pt_init: geom %d references material %d of %d", i, sc->geoms[i].materialid, sc->num_materials);
+    if (sc->geoms[i].type < PT_GEOM_SPHERE || sc->geoms[i].type > PT_GEOM_TRIANGLE)
+      return fail("pt_init: geom %d has unknown type %d", i, sc->geoms[i].type);
+  }
   PtOptions opt{};
   if (opt_in) opt = *opt_in;
   PtContext* c = new PtContext();

@@ -44,7 +44,7 @@ struct Geom {
   float inv[12];   // inverseTransform
   float xf[12];    // transform
   float invT[12];  // invTranspose
-  int32_t type;    // 0 sphere, 1 cube (sceneStructs.h:10-13)
+  int32_t type;    // 0 sphere, 1 cube (sceneStructs.h:10-13); 2 triangle (mesh extension): inv[0..8] = world-space v0, v1, v2
   int32_t material;
   int32_t pad[2];
   // Cube only: the world-space normal for each of the 7 values the object-space normal of

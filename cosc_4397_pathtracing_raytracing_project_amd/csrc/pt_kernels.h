@@ -38,6 +38,7 @@ struct SceneTables {
   // Iterations per wavefront batch of the context (>= every BatchInfo::K it launches): sizes the per-iteration RNG hash
   // table in LDS (none beyond 256 iterations, those batches hash per ray).
   int32_t max_batch_iters;
+  int32_t has_triangles;  // mesh extension: some geoms are PT_GEOM_TRIANGLE (the sphere-only chunk specialisation is off)
 };
 
 struct BatchInfo {

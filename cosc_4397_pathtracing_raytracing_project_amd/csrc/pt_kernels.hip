@@ -530,7 +530,8 @@ PT_DEV void run_chunk(const WaveLds& w, int cfirst, int nc, int sfirst, int nsph
 // (costs ~1.3x a pure chunk instead of two pure chunks), otherwise separately.
 template <bool CAM, bool QO, bool EX>
 PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f3 d,
-                             const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab) {
+                             const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const float* qo_tab,
+                             bool tri) {  // tri (wave-uniform): the back list may hold triangles (mesh extension)
   const int sbase = kCandCap - ns;
   int c0 = 0;
   for (; c0 + 64 <= nb; c0 += 64) run_chunk<1, CAM, QO, EX>(w, c0, 64, 0, 0, lane, o, d, nodes, geoms, qo_tab);
@@ -540,7 +541,10 @@ PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f
     return;
   }
   if (rem > 0) run_chunk<1, CAM, QO, EX>(w, c0, rem, 0, 0, lane, o, d, nodes, geoms, qo_tab);
-  for (int s0 = 0; s0 < ns; s0 += 64) run_chunk<0, CAM, QO, EX>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
+  for (int s0 = 0; s0 < ns; s0 += 64) {
+    if (tri) run_chunk<-1, CAM, QO, EX>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
+    else run_chunk<0, CAM, QO, EX>(w, 0, 0, sbase + s0, min(64, ns - s0), lane, o, d, nodes, geoms, qo_tab);
+  }
 }
 
 // Phase 1 + phase 2 for one group of 64 rays (one per lane; `valid` masks tail lanes).  On return
@@ -550,7 +554,7 @@ PT_DEV void flush_candidates(const WaveLds& w, int nb, int ns, int lane, f3 o, f
 template <bool CAM, bool QO, bool EX>
 PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, float cull,
-                        unsigned long long top_xor, const float* qo_tab = nullptr) {
+                        unsigned long long top_xor, const float* qo_tab = nullptr, bool tri = false) {
   const RayInv ri = Ar<EX>::ray_inv(d, o);
   w.best[lane] = kNoHit;
   int nb = 0, ns = 0;  // pending cubes (front of the list) / spheres (back)
@@ -568,7 +572,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const unsigned long long m = __ballot(pass);
       if (m) {
         if (nb + ns + 64 > kCandCap) {
-          flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+          flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab, tri);
           nb = ns = 0;
         }
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -619,7 +623,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
       if (mb | msp) {
         if (nb + ns + 128 > kCandCap) {
-          flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+          flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab, tri);
           nb = ns = 0;
         }
         const uint32_t entry = ((uint32_t)at_n << 6) | (uint32_t)wk.own;
@@ -633,7 +637,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       }
     }
   }
-  if (nb + ns) flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab);
+  if (nb + ns) flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab, tri);
 }
 
 template <bool TABLES_IN_LDS, bool EX>
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
       no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
       nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
     }
-    trace_group<false, false, EX>(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor);
+    trace_group<false, false, EX>(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, nullptr, sc.has_triangles != 0);
 
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1293,7 +1297,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
     const bool near_scene = __ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (near_scene) trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo);
+    if (near_scene) trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
     else w.best[lane] = kNoHit;
     flush_deferred(df, qbase, out);  // the previous chunk's survivors (see Deferred)
     const unsigned long long best = w.best[lane];

@@ -213,16 +213,27 @@ void parseMaterial(std::istream& in, const std::string& idWord, std::vector<PtMa
   mats.push_back(m);
 }
 // OBJECT block: type line, "material N", then TRANS/ROTAT/SCALE until a blank line (scene.cpp:35-90)
-void parseObject(std::istream& in, const std::string& idWord, std::vector<PtGeom>& geoms) {
-  if (atoi(idWord.c_str()) != (int)geoms.size()) return;
+//
+// Mesh EXTENSION (the format names "mesh", INSTRUCTION.md:246, the reference implements neither loader
+// nor kernel for it): an OBJECT of type `mesh` may carry `TRI x0 y0 z0 x1 y1 z1 x2 y2 z2` lines (object space) among its
+// TRANS / ROTAT / SCALE lines — lines the reference's loader skips (scene.cpp:66-80) — and expands into one PT_GEOM_TRIANGLE
+// primitive per line, vertices transformed to world space with the object's matrix.  OBJECT ids are checked against the
+// number of objects accepted so far (`objects`), which equals geoms.size() (the reference's check, scene.cpp:37) as long as
+// no mesh has expanded.
+void parseObject(std::istream& in, const std::string& idWord, std::vector<PtGeom>& geoms, int& objects) {
+  if (atoi(idWord.c_str()) != objects) return;
+  ++objects;
   PtGeom g{};
   g.type = PT_GEOM_SPHERE;
   float trs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // GLM vec3 members default to zero
   std::string line;
+  bool mesh = false;
+  std::vector<float> tri;  // 9 floats per TRI line
   readLine(in, line);
   if (!line.empty() && in.good()) {
     if (line == "sphere") g.type = PT_GEOM_SPHERE;
     else if (line == "cube") g.type = PT_GEOM_CUBE;
+    else if (line == "mesh") mesh = true;
   }
   readLine(in, line);
   if (!line.empty() && in.good()) {
@@ -235,8 +246,25 @@ void parseObject(std::istream& in, const std::string& idWord, std::vector<PtGeom
     if (w[0] == "TRANS") read3(w, trs + 0);
     else if (w[0] == "ROTAT") read3(w, trs + 3);
     else if (w[0] == "SCALE") read3(w, trs + 6);
+    else if (mesh && w[0] == "TRI" && w.size() >= 10)
+      for (size_t k = 1; k <= 9; ++k) tri.push_back(numAt(w, k));
   }
   buildTransform(trs, g.transform, g.inverseTransform, g.invTranspose);
+  if (mesh) {
+    for (size_t k = 0; k + 8 < tri.size(); k += 9) {
+      PtGeom t{};
+      t.type = PT_GEOM_TRIANGLE;
+      t.materialid = g.materialid;
+      for (int v = 0; v < 3; ++v) {
+        const float* p = &tri[k + 3 * v];
+        const float* m = g.transform;  // vec3(transform * vec4(p, 1)) in GLM order: (m0*x + m1*y) + (m2*z + m3*1)
+        for (int r = 0; r < 3; ++r)
+          t.transform[3 * v + r] = (m[0 * 4 + r] * p[0] + m[1 * 4 + r] * p[1]) + (m[2 * 4 + r] * p[2] + m[3 * 4 + r] * 1.0f);
+      }
+      geoms.push_back(t);
+    }
+    return;
+  }
   geoms.push_back(g);
 }
 
@@ -305,13 +333,14 @@ Scene::Scene(const std::string& filename) {
   std::ifstream in(filename.c_str());
   if (!in.is_open()) throw std::runtime_error("cannot read scene file: " + filename);  // scene.cpp:12-15 aborts
   std::string line;
+  int objects = 0;  // OBJECT blocks accepted (see parseObject)
   while (in.good()) {  // scene.cpp:16-32
     readLine(in, line);
     if (line.empty()) continue;
     auto w = splitWords(line);
     if (w.empty()) continue;
     if (w[0] == "MATERIAL") parseMaterial(in, w.size() > 1 ? w[1] : "", materials);
-    else if (w[0] == "OBJECT") parseObject(in, w.size() > 1 ? w[1] : "", geoms);
+    else if (w[0] == "OBJECT") parseObject(in, w.size() > 1 ? w[1] : "", geoms, objects);
     else if (w[0] == "CAMERA") parseCamera(in, *this);
   }
 }
@@ -367,6 +396,18 @@ struct Box {
 };
 Box worldBounds(const PtGeom& g) {  // 8 transformed unit-cube corners
   Box b;
+  if (g.type == PT_GEOM_TRIANGLE) {
+    // mesh extension: the three world-space vertices, padded — an axis-aligned triangle has a flat box, which the
+    // strict slab test (tmax <= tmin rejects, pathtrace.cu:113-128) would never let a ray into
+    for (int a = 0; a < 3; ++a) {
+      const float v0 = g.transform[a], v1 = g.transform[3 + a], v2 = g.transform[6 + a];
+      float lo = v0 < v1 ? v0 : v1, hi = v0 > v1 ? v0 : v1;
+      lo = lo < v2 ? lo : v2, hi = hi > v2 ? hi : v2;
+      const float pad = 1e-4f * std::max(1.0f, std::max(std::fabs(lo), std::fabs(hi)));
+      b.lo[a] = lo - pad, b.hi[a] = hi + pad;
+    }
+    return b;
+  }
   for (int a = 0; a < 3; ++a) b.lo[a] = std::numeric_limits<float>::max(), b.hi[a] = -std::numeric_limits<float>::max();
   for (int i = 0; i < 8; ++i) {
     const float c[4] = {(i & 1) ? 0.5f : -0.5f, (i & 2) ? 0.5f : -0.5f, (i & 4) ? 0.5f : -0.5f, 1.0f};

@@ -179,3 +179,50 @@ def write_scene(text: str, path: str) -> str:
     with open(path, "w") as f:
         f.write(text)
     return path
+
+
+def _octahedron_tris(a: float = 0.5) -> List[Tuple[float, ...]]:
+    """Eight outward-facing (counter-clockwise seen from outside) triangles of the octahedron with vertices at +-a."""
+    tris = []
+    for sx in (1, -1):
+        for sy in (1, -1):
+            for sz in (1, -1):
+                v0, v1, v2 = (sx * a, 0.0, 0.0), (0.0, sy * a, 0.0), (0.0, 0.0, sz * a)
+                if sx * sy * sz < 0:
+                    v1, v2 = v2, v1
+                tris.append(v0 + v1 + v2)
+    return tris
+
+
+def _mesh_object(idx: int, material: int, trans, rotat, scale, tris) -> str:
+    f = lambda v: " ".join(_num(x) for x in v)
+    body = "".join("TRI " + " ".join(repr(float(x)) for x in t) + "\n" for t in tris)
+    return (f"OBJECT {idx}\nmesh\nmaterial {material}\nTRANS       {f(trans)}\nROTAT       {f(rotat)}\n"
+            f"SCALE       {f(scale)}\n{body}\n")
+
+
+def mesh_scene_text(res: Tuple[int, int] = (200, 120), iterations: int = 16, depth: int = 8, name: str = "mesh",
+                    grid: int = 0) -> str:
+    """EXTENSION test input (not a reference scene): cornell.txt's box and sphere plus `mesh` objects — a red
+    octahedron, a mirror-material octahedron, an axis-aligned two-triangle quad facing the camera — and a cube AFTER the
+    meshes, whose OBJECT id only matches if mesh objects count as one object each.  grid > 0 adds grid^3 small
+    octahedra (8 triangles each), enough leaves for the global-memory / subtree path."""
+    out: List[str] = []
+    for i, m in enumerate(_CORNELL_MATERIALS):
+        out.append(_material(i, **m))
+    out.append(_camera(res, 45, iterations, depth, name, ("0.0", 5, "10.5"), (0, 5, 0), (0, 1, 0)))
+    idx = 0
+    for kind, mat, t, r, s in _CORNELL_OBJECTS:
+        out.append(_object(idx, kind, mat, t, r, s))
+        idx += 1
+    octa = _octahedron_tris()
+    out.append(_mesh_object(idx, 2, (2, 3, 1), (20, 30, 10), (3, 4, 3), octa)); idx += 1
+    out.append(_mesh_object(idx, 4, ("-2.5", "1.5", 2), (0, 45, 0), (2, 3, 2), octa)); idx += 1
+    quad = [(-0.5, -0.5, 0.0, 0.5, -0.5, 0.0, 0.5, 0.5, 0.0), (-0.5, -0.5, 0.0, 0.5, 0.5, 0.0, -0.5, 0.5, 0.0)]
+    out.append(_mesh_object(idx, 3, (0, 8, -3), (0, 0, 0), (4, 2, 1), quad)); idx += 1
+    out.append(_object(idx, "cube", 1, (3, 1, -2), (0, 25, 0), (2, 2, 2))); idx += 1
+    for k in range(grid ** 3):
+        ix, iy, iz = k % grid, (k // grid) % grid, k // (grid * grid)
+        t = (round((ix - (grid - 1) / 2) * 0.9, 4), round(5.5 + iy * 0.8, 4), round(-3.5 + iz * 0.9, 4))
+        out.append(_mesh_object(idx, 1 + k % 4, t, ((k * 13) % 90, (k * 7) % 90, 0), (".6", ".6", ".6"), octa)); idx += 1
+    return "".join(out)

@@ -32,6 +32,11 @@ extern "C" {
 
 #define PT_GEOM_SPHERE 0 /* sceneStructs.h:10-13 */
 #define PT_GEOM_CUBE 1
+/* EXTENSION (default scenes never contain it): one triangle of a `mesh` object — the type the scene format names
+ * (INSTRUCTION.md:246) and the reference does not implement.  transform[0..8] holds the three WORLD-space vertices
+ * v0.xyz, v1.xyz, v2.xyz, every other matrix element is 0; intersected as glm::intersectRayTriangle does (front faces
+ * only; the header the reference includes at intersections.h:4).  Parity unpinned: tested GPU == oracle. */
+#define PT_GEOM_TRIANGLE 2
 
 /* The fields of `Geom` the renderer reads (sceneStructs.h:20-36). */
 typedef struct PtGeom {

@@ -270,12 +270,20 @@ static mat4 inverseTranspose(const mat4& m) {
 }
 
 // ───────────────────────── scene model (src/sceneStructs.h) ──────────────────
-enum GeomType { SPHERE = 0, CUBE = 1 };  // sceneStructs.h:10-13
+// TRIANGLE is the mesh EXTENSION: the scene format names a third object type, "mesh"
+// (INSTRUCTION.md:246), and intersections.h:4 includes <glm/gtx/intersect.hpp>, but neither the reference's loader nor its
+// kernels implement it.  PARITY UNPINNED — nothing in the reference to compare with; the tests are GPU == this restatement
+// and "no mesh in the scene => reference semantics bit for bit".  Syntax (this build's own): inside an OBJECT block of type
+// `mesh`, after the usual material / TRANS / ROTAT / SCALE lines, any number of `TRI x0 y0 z0 x1 y1 z1 x2 y2 z2` lines in
+// object space (the reference's loader skips unknown lines in that block, scene.cpp:66-80).  Every triangle becomes one
+// primitive (one BVH leaf) with world-space vertices vec3(transform * vec4(v, 1)).
+enum GeomType { SPHERE = 0, CUBE = 1, TRIANGLE = 2 };  // sceneStructs.h:10-13 (+ extension)
 struct Geom {                            // sceneStructs.h:20-36 (only fields that are read)
   int type = SPHERE;
   int materialid = 0;
   vec3 translation, rotation, scale;
   mat4 transform, inverseTransform, invTranspose;
+  vec3 v0, v1, v2;  // TRIANGLE only: world-space vertices
 };
 struct Material {  // sceneStructs.h:38-48 (44 bytes, same field order)
   vec3 color;
@@ -297,6 +305,7 @@ struct BVHNode {  // pathtrace.cu:28-32
   int left, right, geomIndex;
 };
 struct Scene {
+  int objects = 0;  // OBJECT blocks accepted so far (= geoms.size() unless a mesh expanded into several primitives)
   std::vector<Geom> geoms;
   std::vector<Material> materials;
   Camera camera;
@@ -377,13 +386,19 @@ static void loadMaterial(Scene& sc, std::istream& in, const std::string& idtok) 
 // scene.cpp:35-90
 static void loadGeom(Scene& sc, std::istream& in, const std::string& idtok) {
   int id = atoi(idtok.c_str());
-  if (id != (int)sc.geoms.size()) return;
+  // the reference compares with geoms.size() (scene.cpp:37): one geom per object there.  A mesh object expands into
+  // several primitives, so objects are counted separately; without meshes the two counts are the same number.
+  if (id != sc.objects) return;
+  sc.objects++;
   Geom g;
   std::string line;
+  bool mesh = false;
+  std::vector<vec3> tri;  // object-space vertices, three per TRI line
   safeGetline(in, line);
   if (!line.empty() && in.good()) {
     if (line == "sphere") g.type = SPHERE;
     else if (line == "cube") g.type = CUBE;
+    else if (line == "mesh") mesh = true;
   }
   safeGetline(in, line);
   if (!line.empty() && in.good()) {
@@ -396,9 +411,25 @@ static void loadGeom(Scene& sc, std::istream& in, const std::string& idtok) {
     if (t[0] == "TRANS") g.translation = atof3(t);
     else if (t[0] == "ROTAT") g.rotation = atof3(t);
     else if (t[0] == "SCALE") g.scale = atof3(t);
+    else if (mesh && t[0] == "TRI" && t.size() >= 10)
+      for (int k = 0; k < 3; ++k) tri.push_back(vec3((float)atof(t[1 + 3 * k].c_str()), (float)atof(t[2 + 3 * k].c_str()), (float)atof(t[3 + 3 * k].c_str())));
     safeGetline(in, line);
   }
   g.transform = buildTransformationMatrix(g.translation, g.rotation, g.scale);
+  if (mesh) {
+    for (size_t k = 0; k + 2 < tri.size(); k += 3) {
+      Geom tg;
+      tg.type = TRIANGLE;
+      tg.materialid = g.materialid;
+      for (int cc = 0; cc < 4; ++cc) tg.transform[cc] = tg.inverseTransform[cc] = tg.invTranspose[cc] = vec4(0, 0, 0, 0);
+      vec4 a = mul(g.transform, vec4(tri[k].x, tri[k].y, tri[k].z, 1.0f));
+      vec4 b = mul(g.transform, vec4(tri[k + 1].x, tri[k + 1].y, tri[k + 1].z, 1.0f));
+      vec4 c = mul(g.transform, vec4(tri[k + 2].x, tri[k + 2].y, tri[k + 2].z, 1.0f));
+      tg.v0 = vec3(a.x, a.y, a.z), tg.v1 = vec3(b.x, b.y, b.z), tg.v2 = vec3(c.x, c.y, c.z);
+      sc.geoms.push_back(tg);
+    }
+    return;
+  }
   g.inverseTransform = inverse(g.transform);
   g.invTranspose = inverseTranspose(g.transform);
   sc.geoms.push_back(g);
@@ -492,6 +523,19 @@ static void cameraFixup(Scene& sc) {
 
 // ───────────────────────── BVH builder (src/pathtrace.cu:34-111) ─────────────
 static AABB computeBounds(const Geom& g) {
+  if (g.type == TRIANGLE) {
+    // the three vertices, padded: an axis-aligned triangle has a flat box, which the strict slab test
+    // (tmax <= tmin rejects, pathtrace.cu:113-128) would never let a ray into
+    AABB box;
+    box.min = vmin(vmin(g.v0, g.v1), g.v2);
+    box.max = vmax(vmax(g.v0, g.v1), g.v2);
+    const float pad[3] = {1e-4f * std::max(1.0f, std::max(fabsf(box.min.x), fabsf(box.max.x))),
+                          1e-4f * std::max(1.0f, std::max(fabsf(box.min.y), fabsf(box.max.y))),
+                          1e-4f * std::max(1.0f, std::max(fabsf(box.min.z), fabsf(box.max.z)))};
+    box.min = vec3(box.min.x - pad[0], box.min.y - pad[1], box.min.z - pad[2]);
+    box.max = vec3(box.max.x + pad[0], box.max.y + pad[1], box.max.z + pad[2]);
+    return box;
+  }
   static const float C[8][3] = {{-0.5f, -0.5f, -0.5f}, {+0.5f, -0.5f, -0.5f}, {-0.5f, +0.5f, -0.5f},
                                 {+0.5f, +0.5f, -0.5f}, {-0.5f, -0.5f, +0.5f}, {+0.5f, -0.5f, +0.5f},
                                 {-0.5f, +0.5f, +0.5f}, {+0.5f, +0.5f, +0.5f}};
@@ -645,6 +689,32 @@ static float boxIntersectionTest(const Geom& box, const Ray& r, vec3& intersecti
   }
   return -1;
 }
+// Mesh extension: glm::intersectRayTriangle as vendored with the reference (external/include/glm/gtx/intersect.inl:37-74,
+// GLM 0.9.6: Moeller-Trumbore, front faces only — `a < epsilon` rejects back faces and edge-on rays), on world-space
+// vertices; hit point, normal and returned distance in the conventions of the box / sphere tests (getPointOnRay pulls the
+// point back by 1e-4 along the ray, the normal faces the ray, the distance is measured to that point).
+static float triangleIntersectionTest(const Geom& tri, const Ray& r, vec3& intersectionPoint, vec3& normal, bool& outside) {
+  const vec3 e1 = tri.v1 - tri.v0;
+  const vec3 e2 = tri.v2 - tri.v0;
+  const vec3 p = cross(r.direction, e2);
+  const float a = dot(e1, p);
+  if (a < std::numeric_limits<float>::epsilon()) return -1;
+  const float f = 1.0f / a;
+  const vec3 s = r.origin - tri.v0;
+  const float bx = f * dot(s, p);
+  if (bx < 0.0f) return -1;
+  if (bx > 1.0f) return -1;
+  const vec3 q = cross(s, e1);
+  const float by = f * dot(r.direction, q);
+  if (by < 0.0f) return -1;
+  if (by + bx > 1.0f) return -1;
+  const float t = f * dot(e2, q);
+  if (!(t >= 0.0f)) return -1;
+  intersectionPoint = getPointOnRay(r, t);
+  normal = normalize(cross(e1, e2));
+  outside = true;
+  return length(r.origin - intersectionPoint);
+}
 // intersections.h:102-144
 static float sphereIntersectionTest(const Geom& sphere, const Ray& r, vec3& intersectionPoint, vec3& normal,
                                     bool& outside) {
@@ -724,8 +794,9 @@ static void computeIntersection(const Scene& sc, const Ray& ray, Hit& hit, Trave
       vec3 pt, nrm;
       bool out = false;
       if (st) st->prim_tests++;
-      float t = (sc.geoms[g].type == CUBE) ? boxIntersectionTest(sc.geoms[g], ray, pt, nrm, out)
-                                          : sphereIntersectionTest(sc.geoms[g], ray, pt, nrm, out);
+      float t = (sc.geoms[g].type == CUBE)       ? boxIntersectionTest(sc.geoms[g], ray, pt, nrm, out)
+                : (sc.geoms[g].type == TRIANGLE) ? triangleIntersectionTest(sc.geoms[g], ray, pt, nrm, out)
+                                                 : sphereIntersectionTest(sc.geoms[g], ray, pt, nrm, out);
       if (t > 0 && t < t_min) {
         t_min = t;
         hitG = g;
@@ -967,6 +1038,10 @@ int orc_scene_set(const OrcGeom* geoms, int ng, const OrcMaterial* mats, int nm,
     f2m(geoms[i].transform, g.transform);
     f2m(geoms[i].inverseTransform, g.inverseTransform);
     f2m(geoms[i].invTranspose, g.invTranspose);
+    if (g.type == TRIANGLE) {  // flat layout: transform[0..8] = v0, v1, v2 (world space)
+      const float* v = geoms[i].transform;
+      g.v0 = vec3(v[0], v[1], v[2]), g.v1 = vec3(v[3], v[4], v[5]), g.v2 = vec3(v[6], v[7], v[8]);
+    }
     g_scene.geoms.push_back(g);
   }
   for (int i = 0; i < nm; ++i) {
@@ -1008,6 +1083,10 @@ void orc_get_geoms(OrcGeom* out) {
     m2f(g.transform, out[i].transform);
     m2f(g.inverseTransform, out[i].inverseTransform);
     m2f(g.invTranspose, out[i].invTranspose);
+    if (g.type == TRIANGLE) {
+      const float v[9] = {g.v0.x, g.v0.y, g.v0.z, g.v1.x, g.v1.y, g.v1.z, g.v2.x, g.v2.y, g.v2.z};
+      for (int k = 0; k < 16; ++k) out[i].transform[k] = k < 9 ? v[k] : 0.0f;
+    }
   }
 }
 void orc_get_materials(OrcMaterial* out) {
@@ -1100,7 +1179,8 @@ float orc_geom_test(int g, const float* o, const float* d, float* point, float* 
   vec3 p, n;
   bool out = false;
   const Geom& G = g_scene.geoms[g];
-  float t = (G.type == CUBE) ? boxIntersectionTest(G, r, p, n, out) : sphereIntersectionTest(G, r, p, n, out);
+  float t = (G.type == CUBE) ? boxIntersectionTest(G, r, p, n, out)
+            : (G.type == TRIANGLE) ? triangleIntersectionTest(G, r, p, n, out) : sphereIntersectionTest(G, r, p, n, out);
   v2f(p, point);
   v2f(n, normal);
   *outside = out;
