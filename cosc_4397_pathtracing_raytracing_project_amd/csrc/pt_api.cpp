@@ -32,6 +32,7 @@ constexpr bool kAblateBuild = false;  // release library: pt_init rejects them
 #endif
 
 std::string g_err;
+constexpr int kBigKernelNodes = 2048;  // see tables(): scenes from this many BVH nodes on run depths >= 1 in k_bounce_big
 }  // namespace
 int pt_fail(const char* fmt, ...) {  // pt_internal.h: sets pt_last_error(), returns -1
   char buf[1024];
@@ -280,6 +281,8 @@ ptk::SceneTables tables(const Ctx& g) {
   t.lds_table_bytes = g.lds_table_bytes;
   t.max_batch_iters = g.K;
   t.has_triangles = g.has_triangles ? 1 : 0;
+  // k_bounce_big from kBigKernelNodes nodes on; debug_flags 64 / 128 force k_bounce<false> / k_bounce_big (A/B, same results)
+  t.big_kernel = (g.debug_flags & 64) ? 0 : ((g.debug_flags & 128) ? 1 : (g.num_nodes >= kBigKernelNodes ? 1 : 0));
   return t;
 }
 

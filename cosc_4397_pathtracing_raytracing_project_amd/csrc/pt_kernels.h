@@ -38,6 +38,9 @@ struct SceneTables {
   // Iterations per wavefront batch of the context (>= every BatchInfo::K it launches): sizes the per-iteration RNG hash
   // table in LDS (none beyond 256 iterations, those batches hash per ray).
   int32_t max_batch_iters;
+  // Host-side choice of the depth >= 1 kernel for scenes whose tables are not in LDS: 1 = k_bounce_big (one group at a
+  // time per wave, 6 waves per SIMD: scenes with deep subtrees, bound by the latency of the per-lane scans), 0 = k_bounce<false>.
+  int32_t big_kernel;
   int32_t has_triangles;  // mesh extension: some geoms are PT_GEOM_TRIANGLE (the sphere-only chunk specialisation is off)
 };
 

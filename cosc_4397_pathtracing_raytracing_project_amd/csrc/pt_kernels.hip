@@ -986,11 +986,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
 constexpr int kRing = 128;  // ring entries per wave (power of two; <= 63 pending + <= 64 appended at once)
 // SMALL: the LDS-table kernels (every leaf is one of <= 32 top entries, so leaf indices are < 64): 16-bit ring entries and
 // no work-stealing table — 7424 B per wave instead of 7936, which is what lets a fifth workgroup of k_bounce fit a CU.
-template <bool SMALL>
+// NPAR: 2 = keys / records / rays double-buffered by group parity (k_bounce: a group is shaded while the next one is
+// searched); 1 = one group at a time (k_bounce_big).
+template <bool SMALL, int NPAR = 2>
 struct Carry {
   using Ent = typename std::conditional<SMALL, uint16_t, uint32_t>::type;
-  unsigned long long* best;  // [2][64]
-  float* rec;                // [2][6][64]  normal xyz, point xyz
+  unsigned long long* best;  // [NPAR][64]
+  float* rec;                // [NPAR][6][64]  normal xyz, point xyz
   Ent* ent;                  // [kRing]     (leaf << 7) | (parity << 6) | owner lane
   float* ray;                // [2][6][64]  origin xyz, direction xyz of each lane's ray, by group parity
   int* slot;                 // [64]        scratch of the work-stealing step (carry_search); not SMALL only
@@ -998,25 +1000,25 @@ struct Carry {
   int appended, processed;   // running totals (wave-uniform)
   int debug;                 // BatchInfo::debug
 };
-template <bool SMALL>
+template <bool SMALL, int NPAR = 2>
 __host__ __device__ constexpr int carry_bytes() {
-  return 2 * 64 * 8 + 2 * 6 * 64 * 4 + kRing * (SMALL ? 2 : 4) + 2 * 6 * 64 * 4 + (SMALL ? 0 : 64 * 4);
+  return NPAR * 64 * 8 + NPAR * 6 * 64 * 4 + kRing * (SMALL ? 2 : 4) + NPAR * 6 * 64 * 4 + (SMALL ? 0 : 64 * 4);
 }
-template <bool SMALL>
-PT_DEV Carry<SMALL> carry_init(char* base) {
-  Carry<SMALL> c;
+template <bool SMALL, int NPAR = 2>
+PT_DEV Carry<SMALL, NPAR> carry_init(char* base) {
+  Carry<SMALL, NPAR> c;
   c.best = reinterpret_cast<unsigned long long*>(base);
-  c.rec = reinterpret_cast<float*>(base + 2 * 64 * 8);
-  c.ray = reinterpret_cast<float*>(base + 2 * 64 * 8 + 2 * 6 * 64 * 4);
-  c.ent = reinterpret_cast<typename Carry<SMALL>::Ent*>(base + 2 * 64 * 8 + 2 * 2 * 6 * 64 * 4);
-  c.slot = reinterpret_cast<int*>(base + 2 * 64 * 8 + 2 * 2 * 6 * 64 * 4 + kRing * 4);
+  c.rec = reinterpret_cast<float*>(base + NPAR * 64 * 8);
+  c.ray = reinterpret_cast<float*>(base + NPAR * 64 * 8 + NPAR * 6 * 64 * 4);
+  c.ent = reinterpret_cast<typename Carry<SMALL, NPAR>::Ent*>(base + NPAR * 64 * 8 + 2 * NPAR * 6 * 64 * 4);
+  c.slot = reinterpret_cast<int*>(base + NPAR * 64 * 8 + 2 * NPAR * 6 * 64 * 4 + kRing * 4);
   c.head = c.count = c.appended = c.processed = 0;
   c.debug = 0;
   return c;
 }
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
-template <bool SMALL>
-PT_DEV void carry_chunk(Carry<SMALL>& c, int n, int lane, const ptd::Node* __restrict__ nodes,
+template <bool SMALL, int NPAR>
+PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
   const int idx = (c.head + lane) & (kRing - 1);
@@ -1048,15 +1050,15 @@ PT_DEV void carry_chunk(Carry<SMALL>& c, int n, int lane, const ptd::Node* __res
 }
 // Append the lanes with `pass` (entry: leaf index, group parity, lane that owns the ray); runs a chunk as soon
 // as 64 entries are pending.  Wave-uniform control flow.
-template <bool SMALL>
-PT_DEV void carry_append(Carry<SMALL>& c, bool pass, uint32_t leaf, int par, int owner, int lane,
+template <bool SMALL, int NPAR>
+PT_DEV void carry_append(Carry<SMALL, NPAR>& c, bool pass, uint32_t leaf, int par, int owner, int lane,
                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const unsigned long long m = __ballot(pass);
   if (!m) return;
   const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   if (pass) {
     const int idx = (c.head + c.count + rank) & (kRing - 1);
-    c.ent[idx] = (typename Carry<SMALL>::Ent)((leaf << 7) | ((uint32_t)par << 6) | (uint32_t)owner);
+    c.ent[idx] = (typename Carry<SMALL, NPAR>::Ent)((leaf << 7) | ((uint32_t)par << 6) | (uint32_t)owner);
   }
   const int cnt = __popcll(m);
   c.count += cnt;
@@ -1066,8 +1068,8 @@ PT_DEV void carry_append(Carry<SMALL>& c, bool pass, uint32_t leaf, int par, int
 // Candidate search of one group (phase 1 of trace_group) feeding the ring.
 // SUB: the scene has subtrees below the top list.  The LDS-table kernels are only used for scenes whose leaves all
 // fit the top list (auto_lds_table_limit), so their instantiation drops the subtree scan.
-template <bool SUB>
-PT_DEV void carry_search(Carry<!SUB>& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
+template <bool SUB, int NPAR>
+PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
                          unsigned long long top_xor) {
   const RayInv ri = ray_inv(d, o);
@@ -1102,7 +1104,7 @@ PT_DEV void carry_search(Carry<!SUB>& c, const float4* top, int ntop, const ptd:
         const int te = __builtin_ctz(mask);
         mask &= mask - 1u;
         const uint32_t leaf = __float_as_uint(reinterpret_cast<const float*>(top)[8 * te + 6]);  // TopEntry::idx
-        c.ent[(c.head + c.count + rank) & (kRing - 1)] = (typename Carry<!SUB>::Ent)((leaf << 7) | tag);
+        c.ent[(c.head + c.count + rank) & (kRing - 1)] = (typename Carry<!SUB, NPAR>::Ent)((leaf << 7) | tag);
       }
       const int cnt = __popcll(m);
       c.count += cnt;
@@ -1151,8 +1153,8 @@ PT_DEV void carry_search(Carry<!SUB>& c, const float4* top, int ntop, const ptd:
 }
 // Make sure everything appended up to `mark` has been tested (only runs a partial chunk when the ring
 // did not fill up since).
-template <bool SMALL>
-PT_DEV void carry_drain_to(Carry<SMALL>& c, int mark, int lane, const ptd::Node* __restrict__ nodes,
+template <bool SMALL, int NPAR>
+PT_DEV void carry_drain_to(Carry<SMALL, NPAR>& c, int mark, int lane, const ptd::Node* __restrict__ nodes,
                            const ptd::Geom* __restrict__ geoms) {
   while (c.processed - mark < 0) carry_chunk(c, min(64, c.count), lane, nodes, geoms);
 }
@@ -1409,7 +1411,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
     nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is searched
     const int par = it & 1;
     cy.best[par * 64 + lane] = kNoHit;
-    carry_search<!TABLES_IN_LDS>(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
+    carry_search<!TABLES_IN_LDS, 2>(cy, top, ntop, nodes, geoms, cur.o, cur.d, valid, lane, par, sc.cull_margin, sc.top_xor);
     if (pg.any) carry_drain_to(cy, pg.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
     // vmcnt is one in-order counter: waiting for the prefetched paths at the top of the next iteration would also wait
     // for everything issued after them — this iteration's stores and the reservation atomic, i.e. a full memory round
@@ -1432,6 +1434,89 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
     carry_drain_to(cy, pg.mark, lane, nodes, geoms);
     shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
     flush_deferred(df, qbase, out);
+  }
+}
+
+// ── depth >= 1 for scenes with subtrees below the top list (thousands of primitives) ────────────────
+// Same stages as k_bounce<false>, one group at a time per wave: load, search (ring + chunks as before), drain, shade, emit,
+// with what is needed only at the end (throughput colour, slot) re-read from memory.  k_bounce's pipelining (next group
+// prefetched, previous group pending, survivors deferred, double-buffered LDS) costs ~40 VGPRs and 3.5 KB of LDS per wave and
+// buys nothing when a group takes ~20 us; without it the kernel needs 75 VGPRs and 4.3 KB per wave, which leaves the LDS for
+// the hot part of the scan tree (see scan_fetch).
+#ifndef PT_BIG_WAVES
+#define PT_BIG_WAVES 4
+#endif
+constexpr int kBigWaves = PT_BIG_WAVES;
+__global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
+                                                                const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
+                                                                ptd::PathBuf in, ptd::PathBuf out, float4* __restrict__ final_rgba) {
+  extern __shared__ float4 lds_raw[];
+  char* lds = reinterpret_cast<char*>(lds_raw);
+  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
+  stage16(lds, sc.top, nb_top);
+  stage16(lds + nb_top, sc.mats, nb_mats);
+  const float4* top = reinterpret_cast<const float4*>(lds);
+  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
+  const ptd::Node* nodes = sc.nodes;
+  const ptd::Geom* geoms = sc.geoms;
+  const int tbl = nb_top + nb_mats;
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * carry_bytes<false, 1>());
+  iter_hash_fill(ihash, sc, b, depth);
+  __syncthreads();
+  const int wib = threadIdx.x >> 6;
+  Carry<false, 1> cy = carry_init<false, 1>(lds + tbl + wib * carry_bytes<false, 1>());
+  cy.debug = b.debug;
+  const int ntop = sc.num_top;
+  const int wave = blockIdx.x * kWavesPerBlock + wib;
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
+  const int64_t S = in.stride;
+  const int64_t qbase = (int64_t)q * qs.cap;
+  const float inv_n = 1.0f / (float)b.N;
+  const int last = qs.cap - 64 + lane;
+  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
+  for (int j = r; j * 64 < n_q; j += wq) {
+    const int i = j * 64 + lane;
+    const bool valid = i < n_q;
+    const int64_t at = qbase + min(i, last);
+    {
+      const f3 o = mk(in.o[at], in.o[S + at], in.o[2 * S + at]);
+      const f3 d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
+      cy.best[lane] = kNoHit;
+      carry_search<true, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
+    }
+    while (cy.count > 0) carry_chunk(cy, min(64, cy.count), lane, nodes, geoms);
+    // shade: direction from the wave's LDS ray buffer, colour and slot from memory
+    ShadeIO s;
+    s.o = mk(0.f, 0.f, 0.f);
+    s.d = mk(cy.ray[3 * 64 + lane], cy.ray[4 * 64 + lane], cy.ray[5 * 64 + lane]);
+    s.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
+    s.alive = false;
+    const int slot = in.slot[at];
+    const unsigned long long best = cy.best[lane];
+    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+    Bounce bo;
+    bo.kind = 0;
+    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+    if (valid) {
+      float ht = -1.0f;
+      int hmat = 0;
+      if (hit) {
+        ht = __uint_as_float((uint32_t)(best >> 32));
+        hmat = geoms[nodes[(uint32_t)best].geom].material;
+        hn = mk(cy.rec[0 * 64 + lane], cy.rec[1 * 64 + lane], cy.rec[2 * 64 + lane]);
+        hp = mk(cy.rec[3 * 64 + lane], cy.rec[4 * 64 + lane], cy.rec[5 * 64 + lane]);
+      }
+      int k, p;
+      divmod(slot, b.N, inv_n, k, p);
+      bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, sc, b, depth, k), global_pixel(b, p), ht, hmat, s);
+    }
+    const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, counter, lane);
+    const bool alive = valid && s.alive;
+    if (alive) shade_bounce(bo, hn, hp, s);
+    emit_survivors(res, alive, s, slot, qbase, out);
   }
 }
 
@@ -1556,6 +1641,11 @@ int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool prima
 }
 int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
+int big_lds_bytes(const SceneTables& sc) {
+  return sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * carry_bytes<false, 1>() +
+         iter_hash_entries(sc) * 4;
+}
+bool use_big(const SceneTables& sc) { return sc.big_kernel != 0 && !tables_in_lds(sc); }
 // The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
 bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
 // Stage the scene tables in LDS only if every leaf is a top-list entry and staging does not cost the dominant kernel a
@@ -1599,7 +1689,8 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kBounce:
-      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
+      if (use_big(sc)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big, kBlock, big_lds_bytes(sc));
+      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
       break;
     case kShade:
@@ -1642,7 +1733,8 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
 
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                    const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba) {
-  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
+  if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
+  else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
   else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, carry_bytes<false>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
 }
 

@@ -97,7 +97,8 @@ typedef struct PtOptions {
                            /*    HIP events on the render stream (pt_get_stats)  */
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
   int32_t debug_flags;      /* A-B switches with UNCHANGED results: 16 no closer-hit cull in the subtree scans, 32 no
-                               near-first subtree order.  Bits 0-3 are profiling ablations with WRONG results
+                               near-first subtree order, 64 / 128 force the pipelined / the high-occupancy depth >= 1
+                               kernel for scenes whose tables are not in LDS (default: by BVH size).  Bits 0-3 are profiling ablations with WRONG results
                                (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
                                they exist only in -DPT_ABLATE builds of the library (tools/pmc_ablate.sh) and
                                pt_init fails on them otherwise (pt_library_has_ablations()).  (Environment,

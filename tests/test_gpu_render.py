@@ -60,6 +60,10 @@ def gpu_render(scene_path, res, spp, depth=None, first=1, **kw):
     ("stress_big", (160, 90), 4, 8, dict(debug_flags=16)),
     ("stress_big", (160, 90), 4, 8, dict(debug_flags=32)),
     ("stress_big", (160, 90), 4, 8, dict(debug_flags=48, unfused_bounces=True)),
+    # depth >= 1 kernel choice for global-table scenes is result-neutral: force the pipelined (64) / the high-occupancy (128) one
+    ("stress_big", (160, 90), 4, 8, dict(debug_flags=64)),
+    ("stress_big", (160, 90), 4, 8, dict(debug_flags=128)),
+    ("stress", (160, 90), 6, 8, dict(debug_flags=128, iters_per_batch=2)),
     ("sphere", (256, 256), 16, 4, dict(unfused_primary=True)),
 ])
 def test_image_bit_exact_vs_oracle(scene_dir, oracle, scene, res, spp, depth, kw):
