@@ -72,16 +72,21 @@ template <typename T, typename SrcFn>
 int exchange(PtGroup* g, ncclDataType_t type, int elems_per_pixel, T* root_recv, SrcFn src) {
   if (g->n == 1) return 0;
   NCCL_OK(ncclGroupStart());
-  for (int i = 1; i < g->n; ++i) {
+  int rc = 0;
+  for (int i = 1; i < g->n && !rc; ++i) {  // an error inside the group must still close it
     const size_t count = (size_t)elems_per_pixel * pt_ctx_pixel_count(g->ctx[i]);
-    HIP_OK(hipSetDevice(g->devices[i]));
-    NCCL_OK(ncclSend(src(i), count, type, 0, g->comms[i], (hipStream_t)pt_ctx_stream(g->ctx[i])));
-    HIP_OK(hipSetDevice(g->devices[0]));
-    NCCL_OK(ncclRecv(root_recv + (size_t)elems_per_pixel * g->recv_off[i], count, type, i, g->comms[0],
-                     (hipStream_t)pt_ctx_stream(g->ctx[0])));
+    ncclResult_t r = ncclSuccess;
+    if (hipSetDevice(g->devices[i]) != hipSuccess) rc = pt_fail("hipSetDevice(%d) failed", g->devices[i]);
+    else if ((r = ncclSend(src(i), count, type, 0, g->comms[i], (hipStream_t)pt_ctx_stream(g->ctx[i]))) != ncclSuccess)
+      rc = pt_fail("ncclSend from device %d failed: %s", g->devices[i], ncclGetErrorString(r));
+    else if (hipSetDevice(g->devices[0]) != hipSuccess) rc = pt_fail("hipSetDevice(%d) failed", g->devices[0]);
+    else if ((r = ncclRecv(root_recv + (size_t)elems_per_pixel * g->recv_off[i], count, type, i, g->comms[0],
+                           (hipStream_t)pt_ctx_stream(g->ctx[0]))) != ncclSuccess)
+      rc = pt_fail("ncclRecv from device %d failed: %s", g->devices[i], ncclGetErrorString(r));
   }
-  NCCL_OK(ncclGroupEnd());
-  return 0;
+  const ncclResult_t e = ncclGroupEnd();
+  if (!rc && e != ncclSuccess) rc = pt_fail("ncclGroupEnd failed: %s", ncclGetErrorString(e));
+  return rc;
 }
 
 // Rows of device i (tile order) -> rows i, i+n, ... of the frame, on the root's stream.
