@@ -90,6 +90,12 @@ struct PtContext {
   float cull_margin = 0.f;
   unsigned long long top_xor = 0;  // SceneTables::top_xor
   int lds_table_bytes = -1;        // SceneTables::lds_table_bytes
+  // uniform grid over the leaf boxes (build_grid; SceneTables::grid_*), large evenly spread scenes only
+  uint32_t* d_grid_start = nullptr;
+  ptd::Node* d_grid_items = nullptr;
+  int grid_res[3] = {0, 0, 0};
+  float grid_min[3] = {0, 0, 0}, grid_cs[3] = {0, 0, 0}, grid_inv_cs[3] = {0, 0, 0}, grid_pad = 0.f;
+  bool have_grid = false;
   bool legacy = false;
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
@@ -264,6 +270,94 @@ void pack_rows(const float m16[16], float out12[12]) {
     for (int r = 0; r < 3; ++r) out12[c * 3 + r] = m16[c * 4 + r];
 }
 
+// Uniform grid over the leaf boxes — the traversal structure of our own for large scenes (SceneTables::grid_*).  The
+// reference's median-split BVH (pathtrace.cu:52-111) costs a bounce ray of a 10 000-primitive scene ~60 dependent node
+// fetches below the top list; a grid with about one cell per primitive is walked in ~6 cells.  Results cannot change: a
+// leaf is tested exactly when the ray passes the leaf's own box (pt_device.h), the grid only has to deliver a superset
+// of those leaves, and it does because every leaf is listed in all cells its box grown by `pad` touches — `pad` is orders
+// of magnitude above the rounding of the float cell walk.  Built only when the primitives are spread evenly enough for
+// a grid to pay (references per leaf and per cell bounded); otherwise the BVH scan stays.
+struct GridBuild {
+  int res[3];
+  float gmin[3], cs[3], inv_cs[3], pad;
+  std::vector<uint32_t> start;
+  std::vector<ptd::Node> items;
+};
+bool build_grid(const std::vector<ptd::Node>& nodes, const float root_min[3], const float root_max[3], double density,
+                bool forced, GridBuild& gb) {
+  std::vector<int> leaves;
+  for (size_t i = 0; i < nodes.size(); ++i)
+    if (nodes[i].geom >= 0) leaves.push_back((int)i);
+  if (leaves.empty()) return false;
+  double ext[3], maxext = 0.0;
+  for (int a = 0; a < 3; ++a) maxext = std::max(maxext, (double)root_max[a] - (double)root_min[a]);
+  if (!(maxext > 0.0) || !std::isfinite(maxext)) return false;
+  const double pad = 1e-4 * maxext;
+  double lo[3], vol = 1.0;
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = (double)root_min[a] - 2.0 * pad;
+    ext[a] = ((double)root_max[a] + 2.0 * pad) - lo[a];
+    vol *= ext[a];
+  }
+  const double per_len = std::cbrt(density * (double)leaves.size() / vol);
+  int64_t ncell = 1;
+  for (int a = 0; a < 3; ++a) {
+    gb.res[a] = (int)std::min(512.0, std::max(1.0, std::floor(ext[a] * per_len + 0.5)));
+    gb.gmin[a] = (float)lo[a];
+    gb.cs[a] = (float)(ext[a] / gb.res[a]);
+    gb.inv_cs[a] = (float)(gb.res[a] / ext[a]);
+    ncell *= gb.res[a];
+  }
+  gb.pad = (float)pad;
+  if (ncell > (int64_t)64 * 1024 * 1024) return false;
+  auto cell_range = [&](const ptd::Node& n, int a, int& c0, int& c1) {
+    c0 = (int)std::floor(((double)n.bmin[a] - pad - lo[a]) / ext[a] * gb.res[a]);
+    c1 = (int)std::floor(((double)n.bmax[a] + pad - lo[a]) / ext[a] * gb.res[a]);
+    c0 = std::min(std::max(c0, 0), gb.res[a] - 1);
+    c1 = std::min(std::max(c1, 0), gb.res[a] - 1);
+  };
+  std::vector<uint32_t> count((size_t)ncell + 1, 0);
+  int64_t refs = 0;
+  for (int li : leaves) {
+    int c0[3], c1[3];
+    for (int a = 0; a < 3; ++a) cell_range(nodes[li], a, c0[a], c1[a]);
+    refs += (int64_t)(c1[0] - c0[0] + 1) * (c1[1] - c0[1] + 1) * (c1[2] - c0[2] + 1);
+    if (refs > (int64_t)1 << 22) return false;  // ring entries hold 22-bit record indices
+  }
+  // worth it only for evenly spread primitives of similar size: few cells per leaf, short lists per cell
+  if (!forced && refs > 12 * (int64_t)leaves.size()) return false;
+  for (int li : leaves) {
+    int c0[3], c1[3];
+    for (int a = 0; a < 3; ++a) cell_range(nodes[li], a, c0[a], c1[a]);
+    for (int z = c0[2]; z <= c1[2]; ++z)
+      for (int y = c0[1]; y <= c1[1]; ++y)
+        for (int x = c0[0]; x <= c1[0]; ++x) ++count[(size_t)x + (size_t)gb.res[0] * ((size_t)y + (size_t)gb.res[1] * z)];
+  }
+  uint32_t longest = 0;
+  gb.start.assign((size_t)ncell + 1, 0);
+  for (int64_t c = 0; c < ncell; ++c) {
+    gb.start[c + 1] = gb.start[c] + count[c];
+    longest = std::max(longest, count[c]);
+  }
+  if (!forced && longest > 32) return false;
+  gb.items.assign((size_t)refs, ptd::Node{});
+  std::vector<uint32_t> fill(gb.start.begin(), gb.start.end() - 1);
+  for (int li : leaves) {  // threaded (= reference visiting) order inside every cell
+    int c0[3], c1[3];
+    for (int a = 0; a < 3; ++a) cell_range(nodes[li], a, c0[a], c1[a]);
+    for (int z = c0[2]; z <= c1[2]; ++z)
+      for (int y = c0[1]; y <= c1[1]; ++y)
+        for (int x = c0[0]; x <= c1[0]; ++x) {
+          ptd::Node it = nodes[li];
+          it.skip = li;
+          it.geom = (x > c0[0] ? 1 : 0) | (x < c1[0] ? 2 : 0) | (y > c0[1] ? 4 : 0) | (y < c1[1] ? 8 : 0) | (z > c0[2] ? 16 : 0) |
+                    (z < c1[2] ? 32 : 0);
+          gb.items[fill[(size_t)x + (size_t)gb.res[0] * ((size_t)y + (size_t)gb.res[1] * z)]++] = it;
+        }
+  }
+  return true;
+}
+
 ptk::SceneTables tables(const Ctx& g) {
   ptk::SceneTables t{};
   t.nodes = g.d_nodes;
@@ -283,6 +377,17 @@ ptk::SceneTables tables(const Ctx& g) {
   t.has_triangles = g.has_triangles ? 1 : 0;
   // k_bounce_big from kBigKernelNodes nodes on; debug_flags 64 / 128 force k_bounce<false> / k_bounce_big (A/B, same results)
   t.big_kernel = (g.debug_flags & 64) ? 0 : ((g.debug_flags & 128) ? 1 : (g.num_nodes >= kBigKernelNodes ? 1 : 0));
+  // the grid walk lives in the big kernel; debug_flags 256 builds and uses it for any scene, 512 never (A/B, same results)
+  t.use_grid = g.have_grid && !(g.debug_flags & 512) && !(g.debug_flags & 64) ? 1 : 0;
+  if (t.use_grid) {
+    t.big_kernel = 1;
+    t.lds_table_bytes = -1;  // (a forced grid on a small scene: the big kernel reads the tables from memory)
+    t.grid_start = g.d_grid_start;
+    t.grid_items = g.d_grid_items;
+    for (int a = 0; a < 3; ++a)
+      t.grid_res[a] = g.grid_res[a], t.grid_min[a] = g.grid_min[a], t.grid_cs[a] = g.grid_cs[a], t.grid_inv_cs[a] = g.grid_inv_cs[a];
+    t.grid_pad = g.grid_pad;
+  }
   return t;
 }
 
@@ -542,6 +647,19 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
+  if ((g.num_nodes >= kBigKernelNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
+    GridBuild gb;
+    const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive
+    if (build_grid(nodes, g.root_min, g.root_max, dens ? atof(dens) : 1.0, (g.debug_flags & 256) != 0, gb)) {
+      if (dalloc(g, &g.d_grid_start, gb.start.size()) || dalloc(g, &g.d_grid_items, gb.items.size())) return -1;
+      HIP_OK(hipMemcpy(g.d_grid_start, gb.start.data(), gb.start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(g.d_grid_items, gb.items.data(), gb.items.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
+      for (int a = 0; a < 3; ++a)
+        g.grid_res[a] = gb.res[a], g.grid_min[a] = gb.gmin[a], g.grid_cs[a] = gb.cs[a], g.grid_inv_cs[a] = gb.inv_cs[a];
+      g.grid_pad = gb.pad;
+      g.have_grid = true;
+    }
+  }
 
   {
     const char* kb = getenv("PT_LDS_TABLE_KB");  // test / experiment knob: force the LDS staging limit of the scene tables
@@ -764,6 +882,7 @@ int pt_ctx_get_stats(PtContext* c, PtStats* out) {
   out->primary_fused = g.fuse_primary ? 1 : 0;
   out->bounces_fused = g.fuse_bounces ? 1 : 0;
   out->arith = g.arith;
+  out->grid_cells = (tables(g).use_grid && g.fuse_bounces) ? g.grid_res[0] * g.grid_res[1] * g.grid_res[2] : 0;
   return 0;
 }
 

@@ -41,6 +41,18 @@ struct SceneTables {
   // Host-side choice of the depth >= 1 kernel for scenes whose tables are not in LDS: 1 = k_bounce_big (one group at a
   // time per wave, 6 waves per SIMD: scenes with deep subtrees, bound by the latency of the per-lane scans), 0 = k_bounce<false>.
   int32_t big_kernel;
+  // Uniform grid over the leaf boxes (pt_api.cpp build_grid; grid_search in pt_kernels.hip): the depth >= 1 kernel of large
+  // scenes walks it instead of the BVH when the host finds the primitives evenly spread.  A cell lists every leaf whose box,
+  // grown by grid_pad, overlaps it: cell c's records are grid_items[grid_start[c] .. grid_start[c + 1]), each a ptd::Node
+  // with the leaf's box, `skip` = the leaf's threaded node index and `geom` = bit a set when the leaf is also listed in
+  // the neighbour cell a (0..5 = -x, +x, -y, +y, -z, +z).  A leaf is a candidate exactly when the ray passes its own box
+  // test (pt_device.h, TopEntry), so any structure that finds a superset of those leaves gives the same image.
+  const uint32_t* grid_start;
+  const ptd::Node* grid_items;
+  int32_t grid_res[3];
+  float grid_min[3], grid_cs[3], grid_inv_cs[3];
+  float grid_pad;
+  int32_t use_grid;
   int32_t has_triangles;  // mesh extension: some geoms are PT_GEOM_TRIANGLE (the sphere-only chunk specialisation is off)
 };
 

@@ -1159,6 +1159,116 @@ PT_DEV void carry_drain_to(Carry<SMALL, NPAR>& c, int mark, int lane, const ptd:
   while (c.processed - mark < 0) carry_chunk(c, min(64, c.count), lane, nodes, geoms);
 }
 
+// ── uniform grid walk (SceneTables::grid_*; large scenes with evenly spread primitives) ─────────────────────────────
+// Second ring of a wave: cell records a ray came across, waiting for their leaf-box test.  Entry: record index << 10 |
+// direction the ray entered the cell from (0..5 = through its -x, +x, -y, +y, -z, +z face, 7 = first cell) << 7 |
+// group parity << 6 | owner lane.
+struct CellRing {
+  uint32_t* ent;  // [kRing]
+  int head, count;
+};
+// Leaf-box tests (the mode's slab arithmetic: these decide, exactly like the reference's walk, which primitives a ray is
+// tested against) for the first n (<= 64) pending records; passing leaves go to the primitive ring.  A leaf that is also
+// listed in the cell the ray came from was handled there: a box occupies a block of cells and the ray's cells inside a
+// block are consecutive.  Wave-uniform control flow.
+template <int NPAR>
+PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneTables& sc, int lane,
+                        const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+  const bool valid = lane < n;
+  const uint32_t entry = cr.ent[(cr.head + lane) & (kRing - 1)];
+  const int src = (int)(entry & 63u);
+  const int par = (int)((entry >> 6) & 1u);
+  const int from = (int)((entry >> 7) & 7u);
+  const uint32_t item = valid ? entry >> 10 : 0u;
+  const float* ray = c.ray + par * 6 * 64 + src;
+  const f3 ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
+  const f3 rd = mk(ray[3 * 64], ray[4 * 64], ray[5 * 64]);
+  const float4 NA = reinterpret_cast<const float4*>(sc.grid_items)[2 * item];      // bmin.xyz, bmax.x
+  const float4 NB = reinterpret_cast<const float4*>(sc.grid_items)[2 * item + 1];  // bmax.yz, leaf, neighbour bits
+  const RayInv ri = ray_inv(rd, ro);
+  const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + src) + 1]) + sc.cull_margin;
+  float tn;
+  const bool seen = ((__float_as_uint(NB.w) >> from) & 1u) != 0u;  // from == 7: bit 7 is never set
+  const bool pass = valid && !seen && slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
+  cr.head = (cr.head + n) & (kRing - 1);
+  cr.count -= n;
+  carry_append(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms);
+}
+// Candidate search of one group through the grid: every lane walks its own ray cell by cell (3D-DDA in fast float
+// arithmetic: the walk only has to reach every cell the ray touches, which the padding of the cell lists guarantees),
+// files the records of each cell in the cell ring, and stops at the far side of the grid or once the next cell starts
+// beyond the ray's best hit so far (the closer-hit cull of the subtree scans, same margin + the padding).
+template <int NPAR>
+PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& sc, const ptd::Node* __restrict__ nodes,
+                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
+  {
+    float* ray = c.ray + par * 6 * 64 + lane;
+    ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
+    ray[3 * 64] = d.x, ray[4 * 64] = d.y, ray[5 * 64] = d.z;
+  }
+  const float dx = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), 1e-20f), d.x);
+  const float dy = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), 1e-20f), d.y);
+  const float dz = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), 1e-20f), d.z);
+  const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
+  const int rx = sc.grid_res[0], ry = sc.grid_res[1], rz = sc.grid_res[2];
+  const float gx = sc.grid_min[0], gy = sc.grid_min[1], gz = sc.grid_min[2];
+  const float csx = sc.grid_cs[0], csy = sc.grid_cs[1], csz = sc.grid_cs[2];
+  // the ray's span inside the grid
+  const float ax0 = (gx - o.x) * ix, ax1 = (gx + csx * (float)rx - o.x) * ix;
+  const float ay0 = (gy - o.y) * iy, ay1 = (gy + csy * (float)ry - o.y) * iy;
+  const float az0 = (gz - o.z) * iz, az1 = (gz + csz * (float)rz - o.z) * iz;
+  const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
+                                     __builtin_fmaxf(__builtin_fminf(az0, az1), 0.0f));
+  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fmaxf(az0, az1));
+  bool on = valid && t_out >= t_in;
+  // first cell and the per-axis state: distance of the next cell boundary, distance between boundaries, cells left
+  const float px = o.x + d.x * t_in, py = o.y + d.y * t_in, pz = o.z + d.z * t_in;
+  const int cx = min(max((int)__builtin_floorf((px - gx) * sc.grid_inv_cs[0]), 0), rx - 1);
+  const int cy_ = min(max((int)__builtin_floorf((py - gy) * sc.grid_inv_cs[1]), 0), ry - 1);
+  const int cz = min(max((int)__builtin_floorf((pz - gz) * sc.grid_inv_cs[2]), 0), rz - 1);
+  const bool fx = dx >= 0.0f, fy = dy >= 0.0f, fz = dz >= 0.0f;
+  float tx = (gx + csx * (float)(cx + (fx ? 1 : 0)) - o.x) * ix;
+  float ty = (gy + csy * (float)(cy_ + (fy ? 1 : 0)) - o.y) * iy;
+  float tz = (gz + csz * (float)(cz + (fz ? 1 : 0)) - o.z) * iz;
+  const float ddx = csx * __builtin_fabsf(ix), ddy = csy * __builtin_fabsf(iy), ddz = csz * __builtin_fabsf(iz);
+  int lx = fx ? rx - 1 - cx : cx, ly = fy ? ry - 1 - cy_ : cy_, lz = fz ? rz - 1 - cz : cz;
+  const int sx = fx ? 1 : -1, sy = fy ? rx : -rx, sz = fz ? rx * ry : -(rx * ry);
+  int idx = cx + rx * (cy_ + ry * cz);
+  float te = t_in;
+  uint32_t from = 7u;
+  const uint32_t tag = ((uint32_t)par << 6) | (uint32_t)lane;
+  const float slack = sc.cull_margin + 2.0f * sc.grid_pad;
+  while (true) {
+    const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + lane) + 1]) + slack;
+    on = on && !(te > bt);
+    if (!__ballot(on)) break;
+    const uint2 se = on ? *reinterpret_cast<const uint2*>(sc.grid_start + idx) : make_uint2(0u, 0u);  // 4-byte aligned pair
+    uint32_t it = se.x;
+    while (true) {  // one record per lane and round
+      const bool has = it < se.y;
+      const unsigned long long m = __ballot(has);
+      if (!m) break;
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+      if (has) cr.ent[(cr.head + cr.count + rank) & (kRing - 1)] = (it << 10) | (from << 7) | tag;
+      ++it;
+      cr.count += __popcll(m);
+      if (cr.count >= 64) grid_filter(c, cr, 64, sc, lane, nodes, geoms);
+    }
+    // next cell: through the nearest boundary
+    const bool ax = tx <= ty && tx <= tz;
+    const bool ay = !ax && ty <= tz;
+    const int left = ax ? lx : ay ? ly : lz;
+    if (left == 0) on = false;
+    te = ax ? tx : ay ? ty : tz;
+    idx += ax ? sx : ay ? sy : sz;
+    from = ax ? (fx ? 0u : 1u) : ay ? (fy ? 2u : 3u) : (fz ? 4u : 5u);  // moving +x: entered through the -x face
+    if (ax) tx += ddx, --lx;
+    else if (ay) ty += ddy, --ly;
+    else tz += ddz, --lz;
+  }
+  while (cr.count > 0) grid_filter(c, cr, min(64, cr.count), sc, lane, nodes, geoms);
+}
+
 // State of a group between its search and its shading (one loop iteration later).
 struct Pending {
   f3 d, c;
@@ -1447,12 +1557,13 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
 #define PT_BIG_WAVES 4
 #endif
 constexpr int kBigWaves = PT_BIG_WAVES;
+template <bool GRID>
 __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                                 const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
                                                                 ptd::PathBuf in, ptd::PathBuf out, float4* __restrict__ final_rgba) {
   extern __shared__ float4 lds_raw[];
   char* lds = reinterpret_cast<char*>(lds_raw);
-  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  const int nb_top = GRID ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk replaces top list and subtrees
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
   stage16(lds + nb_top, sc.mats, nb_mats);
@@ -1461,11 +1572,13 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const ptd::Node* nodes = sc.nodes;
   const ptd::Geom* geoms = sc.geoms;
   const int tbl = nb_top + nb_mats;
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * carry_bytes<false, 1>());
+  constexpr int kWaveBytes = carry_bytes<false, 1>() + (GRID ? kRing * 4 : 0);
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);
   iter_hash_fill(ihash, sc, b, depth);
   __syncthreads();
   const int wib = threadIdx.x >> 6;
-  Carry<false, 1> cy = carry_init<false, 1>(lds + tbl + wib * carry_bytes<false, 1>());
+  Carry<false, 1> cy = carry_init<false, 1>(lds + tbl + wib * kWaveBytes);
+  CellRing cr{reinterpret_cast<uint32_t*>(lds + tbl + wib * kWaveBytes + carry_bytes<false, 1>()), 0, 0};
   cy.debug = b.debug;
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
@@ -1485,7 +1598,8 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
       const f3 o = mk(in.o[at], in.o[S + at], in.o[2 * S + at]);
       const f3 d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
       cy.best[lane] = kNoHit;
-      carry_search<true, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
+      if (GRID) grid_search<1>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
+      else carry_search<true, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
     }
     while (cy.count > 0) carry_chunk(cy, min(64, cy.count), lane, nodes, geoms);
     // shade: direction from the wave's LDS ray buffer, colour and slot from memory
@@ -1642,6 +1756,8 @@ int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool prima
 int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
 int big_lds_bytes(const SceneTables& sc) {
+  if (sc.use_grid)
+    return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * (carry_bytes<false, 1>() + kRing * 4) + iter_hash_entries(sc) * 4;
   return sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * carry_bytes<false, 1>() +
          iter_hash_entries(sc) * 4;
 }
@@ -1689,7 +1805,8 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kBounce:
-      if (use_big(sc)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big, kBlock, big_lds_bytes(sc));
+      if (use_big(sc) && sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big<true>, kBlock, big_lds_bytes(sc));
+      else if (use_big(sc)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big<false>, kBlock, big_lds_bytes(sc));
       else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
       break;
@@ -1733,7 +1850,8 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
 
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                    const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba) {
-  if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
+  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL(k_bounce_big<true>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
+  else if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big<false>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
   else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
   else hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, carry_bytes<false>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
 }

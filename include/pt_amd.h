@@ -98,7 +98,9 @@ typedef struct PtOptions {
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
   int32_t debug_flags;      /* A-B switches with UNCHANGED results: 16 no closer-hit cull in the subtree scans, 32 no
                                near-first subtree order, 64 / 128 force the pipelined / the high-occupancy depth >= 1
-                               kernel for scenes whose tables are not in LDS (default: by BVH size).  Bits 0-3 are profiling ablations with WRONG results
+                               kernel for scenes whose tables are not in LDS (default: by BVH size), 256 / 512 force /
+                               forbid the uniform-grid walk of the depth >= 1 kernel (default: large scenes whose
+                               primitives are evenly spread).  Bits 0-3 are profiling ablations with WRONG results
                                (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
                                they exist only in -DPT_ABLATE builds of the library (tools/pmc_ablate.sh) and
                                pt_init fails on them otherwise (pt_library_has_ablations()).  (Environment,
@@ -148,7 +150,8 @@ typedef struct PtStats {
   int32_t bounces_fused;              /* 1: depths >= 1 ran in the fused bounce kernel; the timed launches
                                          (intersect_ms / intersect_launches) are then those kernels      */
   int32_t arith;                      /* PT_ARITH_* in use                                               */
-  int32_t pad_;
+  int32_t grid_cells;                 /* > 0: depths >= 1 walk the uniform grid over the leaf boxes (large, evenly spread
+                                         scenes) with this many cells; 0: the BVH scan                  */
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,

@@ -61,6 +61,7 @@ def test_triangle_test_is_glm_intersect_ray_triangle(oracle, mesh_scene):
     (0, (97, 61), 5, dict(legacy_traversal=True)),
     (4, (160, 96), 4, {}),                               # 64 more octahedra = 538 leaves: global tables, subtree scans
     (4, (160, 96), 4, dict(unfused_bounces=True)),
+    (4, (160, 96), 4, dict(debug_flags=256)),            # forced uniform-grid walk
 ])
 def test_gpu_mesh_bit_exact_vs_oracle(oracle, tmp_path, grid, res, spp, kw):
     path = scenes.write_scene(scenes.mesh_scene_text(res=res, grid=grid), str(tmp_path / "m.txt"))
