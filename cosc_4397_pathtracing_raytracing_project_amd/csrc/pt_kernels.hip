@@ -1163,10 +1163,23 @@ PT_DEV void carry_drain_to(Carry<SMALL, NPAR>& c, int mark, int lane, const ptd:
 // Second ring of a wave: cell records a ray came across, waiting for their leaf-box test.  Entry: record index << 10 |
 // direction the ray entered the cell from (0..5 = through its -x, +x, -y, +y, -z, +z face, 7 = first cell) << 7 |
 // group parity << 6 | owner lane.
+constexpr int kCellRing = 256;  // entries (power of two): what is left of a step (< 64) + what a step files (<= 192 at once)
 struct CellRing {
-  uint32_t* ent;  // [kRing]
+  uint32_t* ent;  // [kCellRing]
   int head, count;
 };
+// Exclusive prefix sum over the wave of a small count (< 64) per lane, and the total: one ballot per bit.
+PT_DEV int wave_prefix6(int v, int& total) {
+  int pre = 0;
+  total = 0;
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    const unsigned long long m = __ballot((v >> b) & 1);
+    pre += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) << b;
+    total += __popcll(m) << b;
+  }
+  return pre;
+}
 // Leaf-box tests (the mode's slab arithmetic: these decide, exactly like the reference's walk, which primitives a ray is
 // tested against) for the first n (<= 64) pending records; passing leaves go to the primitive ring.  A leaf that is also
 // listed in the cell the ray came from was handled there: a box occupies a block of cells and the ray's cells inside a
@@ -1175,7 +1188,7 @@ template <int NPAR>
 PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneTables& sc, int lane,
                         const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
-  const uint32_t entry = cr.ent[(cr.head + lane) & (kRing - 1)];
+  const uint32_t entry = cr.ent[(cr.head + lane) & (kCellRing - 1)];
   const int src = (int)(entry & 63u);
   const int par = (int)((entry >> 6) & 1u);
   const int from = (int)((entry >> 7) & 7u);
@@ -1190,22 +1203,25 @@ PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneT
   float tn;
   const bool seen = ((__float_as_uint(NB.w) >> from) & 1u) != 0u;  // from == 7: bit 7 is never set
   const bool pass = valid && !seen && slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
-  cr.head = (cr.head + n) & (kRing - 1);
+  cr.head = (cr.head + n) & (kCellRing - 1);
   cr.count -= n;
   carry_append(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms);
 }
-// Candidate search of one group through the grid: every lane walks its own ray cell by cell (3D-DDA in fast float
-// arithmetic: the walk only has to reach every cell the ray touches, which the padding of the cell lists guarantees),
-// files the records of each cell in the cell ring, and stops at the far side of the grid or once the next cell starts
-// beyond the ray's best hit so far (the closer-hit cull of the subtree scans, same margin + the padding).
-template <int NPAR>
-PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& sc, const ptd::Node* __restrict__ nodes,
-                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
-  {
-    float* ray = c.ray + par * 6 * 64 + lane;
-    ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
-    ray[3 * 64] = d.x, ray[4 * 64] = d.y, ray[5 * 64] = d.z;
-  }
+// State of a lane's cell walk (3D-DDA): the distance along the ray of the next cell boundary per axis, the distance
+// between boundaries, the cells left before the grid ends, the current cell.
+struct CellWalk {
+  float tx, ty, tz, ddx, ddy, ddz;
+  int lx, ly, lz;
+  bool fx, fy, fz;  // moving towards +x / +y / +z
+  int idx;
+  float te, t_end;  // entry distance of the current cell; the walk covers [te, t_end]
+  uint32_t from;    // face the current cell was entered through (grid_filter), 7: first cell of a walk
+  int own;          // lane that owns the ray
+  bool on;
+};
+// Start a walk of ray (o, d) over the part [t_from, t_to] of its span inside the grid.  Fast float arithmetic in every
+// mode: the walk only has to reach every cell the ray touches, which the padding of the cell lists guarantees.
+PT_DEV void walk_start(const SceneTables& sc, f3 o, f3 d, float t_from, float t_to, bool want, int own, CellWalk& w) {
   const float dx = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), 1e-20f), d.x);
   const float dy = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), 1e-20f), d.y);
   const float dz = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), 1e-20f), d.z);
@@ -1213,58 +1229,107 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
   const int rx = sc.grid_res[0], ry = sc.grid_res[1], rz = sc.grid_res[2];
   const float gx = sc.grid_min[0], gy = sc.grid_min[1], gz = sc.grid_min[2];
   const float csx = sc.grid_cs[0], csy = sc.grid_cs[1], csz = sc.grid_cs[2];
-  // the ray's span inside the grid
   const float ax0 = (gx - o.x) * ix, ax1 = (gx + csx * (float)rx - o.x) * ix;
   const float ay0 = (gy - o.y) * iy, ay1 = (gy + csy * (float)ry - o.y) * iy;
   const float az0 = (gz - o.z) * iz, az1 = (gz + csz * (float)rz - o.z) * iz;
   const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                     __builtin_fmaxf(__builtin_fminf(az0, az1), 0.0f));
-  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)), __builtin_fmaxf(az0, az1));
-  bool on = valid && t_out >= t_in;
-  // first cell and the per-axis state: distance of the next cell boundary, distance between boundaries, cells left
+                                     __builtin_fmaxf(__builtin_fminf(az0, az1), t_from));
+  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
+                                      __builtin_fminf(__builtin_fmaxf(az0, az1), t_to));
+  w.on = want && t_out >= t_in;
   const float px = o.x + d.x * t_in, py = o.y + d.y * t_in, pz = o.z + d.z * t_in;
   const int cx = min(max((int)__builtin_floorf((px - gx) * sc.grid_inv_cs[0]), 0), rx - 1);
-  const int cy_ = min(max((int)__builtin_floorf((py - gy) * sc.grid_inv_cs[1]), 0), ry - 1);
+  const int cy = min(max((int)__builtin_floorf((py - gy) * sc.grid_inv_cs[1]), 0), ry - 1);
   const int cz = min(max((int)__builtin_floorf((pz - gz) * sc.grid_inv_cs[2]), 0), rz - 1);
-  const bool fx = dx >= 0.0f, fy = dy >= 0.0f, fz = dz >= 0.0f;
-  float tx = (gx + csx * (float)(cx + (fx ? 1 : 0)) - o.x) * ix;
-  float ty = (gy + csy * (float)(cy_ + (fy ? 1 : 0)) - o.y) * iy;
-  float tz = (gz + csz * (float)(cz + (fz ? 1 : 0)) - o.z) * iz;
-  const float ddx = csx * __builtin_fabsf(ix), ddy = csy * __builtin_fabsf(iy), ddz = csz * __builtin_fabsf(iz);
-  int lx = fx ? rx - 1 - cx : cx, ly = fy ? ry - 1 - cy_ : cy_, lz = fz ? rz - 1 - cz : cz;
-  const int sx = fx ? 1 : -1, sy = fy ? rx : -rx, sz = fz ? rx * ry : -(rx * ry);
-  int idx = cx + rx * (cy_ + ry * cz);
-  float te = t_in;
-  uint32_t from = 7u;
-  const uint32_t tag = ((uint32_t)par << 6) | (uint32_t)lane;
+  w.fx = dx >= 0.0f, w.fy = dy >= 0.0f, w.fz = dz >= 0.0f;
+  w.tx = (gx + csx * (float)(cx + (w.fx ? 1 : 0)) - o.x) * ix;
+  w.ty = (gy + csy * (float)(cy + (w.fy ? 1 : 0)) - o.y) * iy;
+  w.tz = (gz + csz * (float)(cz + (w.fz ? 1 : 0)) - o.z) * iz;
+  w.ddx = csx * __builtin_fabsf(ix), w.ddy = csy * __builtin_fabsf(iy), w.ddz = csz * __builtin_fabsf(iz);
+  w.lx = w.fx ? rx - 1 - cx : cx, w.ly = w.fy ? ry - 1 - cy : cy, w.lz = w.fz ? rz - 1 - cz : cz;
+  w.idx = cx + rx * (cy + ry * cz);
+  w.te = t_in;
+  w.t_end = t_out;
+  w.from = 7u;
+  w.own = own;
+}
+// Candidate search of one group through the grid: every lane walks its own ray cell by cell, files the records of each
+// cell in the cell ring, and stops at the far side of the grid or once the next cell starts beyond the ray's best hit so
+// far (the closer-hit cull of the subtree scans, same margin + the padding).  Rays hit after 6 cells on average but the
+// longest of 64 walks takes 26, so once few lanes are still walking their remaining spans are cut into equal parts and
+// dealt to all 64 lanes (candidates are filed under the lane that owns the ray, as with the work stealing of the
+// subtree scans; the parts overlap by a cell, which costs a repeated test and changes nothing).
+#ifndef PT_GRID_SPLIT
+#define PT_GRID_SPLIT 16
+#endif
+constexpr int kGridSplit = PT_GRID_SPLIT;  // lanes still walking when the remaining spans are dealt out (0: never)
+template <int NPAR>
+PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& sc, const ptd::Node* __restrict__ nodes,
+                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
+  float* rays = c.ray + par * 6 * 64;
+  rays[0 * 64 + lane] = o.x, rays[1 * 64 + lane] = o.y, rays[2 * 64 + lane] = o.z;
+  rays[3 * 64 + lane] = d.x, rays[4 * 64 + lane] = d.y, rays[5 * 64 + lane] = d.z;
+  CellWalk w;
+  walk_start(sc, o, d, 0.0f, FLT_MAX, valid, lane, w);
+  const int rx = sc.grid_res[0], rxy = sc.grid_res[0] * sc.grid_res[1];
   const float slack = sc.cull_margin + 2.0f * sc.grid_pad;
+  int splits = 0;
   while (true) {
-    const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + lane) + 1]) + slack;
-    on = on && !(te > bt);
-    if (!__ballot(on)) break;
-    const uint2 se = on ? *reinterpret_cast<const uint2*>(sc.grid_start + idx) : make_uint2(0u, 0u);  // 4-byte aligned pair
+    const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + w.own) + 1]) + slack;
+    w.on = w.on && !(w.te > bt) && !(w.te > w.t_end);
+    const unsigned long long M = __ballot(w.on);
+    if (!M) break;
+    if (kGridSplit > 0 && splits < 2 && __popcll(M) <= kGridSplit) {
+      ++splits;
+      const int n_on = __popcll(M);
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0));
+      if (w.on) c.slot[rank] = lane;
+      const int k = 64 / n_on;
+      const int r = lane / k, seg = lane - r * k;
+      const bool take = r < n_on;
+      const int donor = c.slot[take ? r : 0];
+      const float d_te = bperm(donor, w.te), d_end = bperm(donor, w.t_end);
+      const int d_own = __builtin_amdgcn_ds_bpermute(donor << 2, w.own);
+      const f3 so = mk(rays[0 * 64 + d_own], rays[1 * 64 + d_own], rays[2 * 64 + d_own]);
+      const f3 sd = mk(rays[3 * 64 + d_own], rays[4 * 64 + d_own], rays[5 * 64 + d_own]);
+      const float part = (d_end - d_te) / (float)k;
+      const float ta = d_te + part * (float)seg;
+      const float tb = seg == k - 1 ? d_end : ta + part;
+      walk_start(sc, so, sd, ta, tb, take, d_own, w);
+    }
+    const uint2 se = w.on ? *reinterpret_cast<const uint2*>(sc.grid_start + w.idx) : make_uint2(0u, 0u);  // 4-byte aligned pair
+    const uint32_t tag = (w.from << 7) | ((uint32_t)par << 6) | (uint32_t)w.own;
+    // File the cells' records, a cell's records next to each other: the lanes of a box-test chunk then read neighbouring
+    // 32-byte records (one L1 access per 128-byte line instead of one per lane — the L1's access rate is what bounds
+    // this kernel).  Ring positions from a prefix sum over the lanes' list lengths; a step files at most 192 records at
+    // once, a lane up to 63 (longer lists and later lanes take another turn).
     uint32_t it = se.x;
-    while (true) {  // one record per lane and round
-      const bool has = it < se.y;
-      const unsigned long long m = __ballot(has);
-      if (!m) break;
-      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-      if (has) cr.ent[(cr.head + cr.count + rank) & (kRing - 1)] = (it << 10) | (from << 7) | tag;
-      ++it;
-      cr.count += __popcll(m);
-      if (cr.count >= 64) grid_filter(c, cr, 64, sc, lane, nodes, geoms);
+    while (true) {
+      const int want = (int)min(se.y - it, 63u);
+      int total;
+      const int pre = wave_prefix6(want, total);
+      if (total == 0) break;
+      const bool now = pre + want <= kCellRing - 64;
+      const int take = now ? want : 0;
+      const int base = cr.head + cr.count + pre;
+      for (int j = 0; j < take; ++j) cr.ent[(base + j) & (kCellRing - 1)] = ((it + (uint32_t)j) << 10) | tag;
+      it += (uint32_t)take;
+      // the lanes that filed are a prefix of the lanes (pre grows with the lane index): the last one knows the sum
+      const unsigned long long nm = __ballot(now);
+      if (nm) cr.count += __builtin_amdgcn_readlane(pre + want, 63 - __builtin_clzll(nm));
+      while (cr.count >= 64) grid_filter(c, cr, 64, sc, lane, nodes, geoms);
     }
     // next cell: through the nearest boundary
-    const bool ax = tx <= ty && tx <= tz;
-    const bool ay = !ax && ty <= tz;
-    const int left = ax ? lx : ay ? ly : lz;
-    if (left == 0) on = false;
-    te = ax ? tx : ay ? ty : tz;
-    idx += ax ? sx : ay ? sy : sz;
-    from = ax ? (fx ? 0u : 1u) : ay ? (fy ? 2u : 3u) : (fz ? 4u : 5u);  // moving +x: entered through the -x face
-    if (ax) tx += ddx, --lx;
-    else if (ay) ty += ddy, --ly;
-    else tz += ddz, --lz;
+    const bool ax = w.tx <= w.ty && w.tx <= w.tz;
+    const bool ay = !ax && w.ty <= w.tz;
+    const int left = ax ? w.lx : ay ? w.ly : w.lz;
+    if (left == 0) w.on = false;
+    w.te = ax ? w.tx : ay ? w.ty : w.tz;
+    w.idx += ax ? (w.fx ? 1 : -1) : ay ? (w.fy ? rx : -rx) : (w.fz ? rxy : -rxy);
+    w.from = ax ? (w.fx ? 0u : 1u) : ay ? (w.fy ? 2u : 3u) : (w.fz ? 4u : 5u);  // moving +x: entered through the -x face
+    if (ax) w.tx += w.ddx, --w.lx;
+    else if (ay) w.ty += w.ddy, --w.ly;
+    else w.tz += w.ddz, --w.lz;
   }
   while (cr.count > 0) grid_filter(c, cr, min(64, cr.count), sc, lane, nodes, geoms);
 }
@@ -1572,7 +1637,7 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const ptd::Node* nodes = sc.nodes;
   const ptd::Geom* geoms = sc.geoms;
   const int tbl = nb_top + nb_mats;
-  constexpr int kWaveBytes = carry_bytes<false, 1>() + (GRID ? kRing * 4 : 0);
+  constexpr int kWaveBytes = carry_bytes<false, 1>() + (GRID ? kCellRing * 4 : 0);
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);
   iter_hash_fill(ihash, sc, b, depth);
   __syncthreads();
@@ -1757,7 +1822,7 @@ int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
 int big_lds_bytes(const SceneTables& sc) {
   if (sc.use_grid)
-    return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * (carry_bytes<false, 1>() + kRing * 4) + iter_hash_entries(sc) * 4;
+    return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * (carry_bytes<false, 1>() + kCellRing * 4) + iter_hash_entries(sc) * 4;
   return sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * carry_bytes<false, 1>() +
          iter_hash_entries(sc) * 4;
 }
