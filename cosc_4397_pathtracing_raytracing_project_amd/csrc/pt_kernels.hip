@@ -1017,7 +1017,7 @@ PT_DEV Carry<SMALL, NPAR> carry_init(char* base) {
   return c;
 }
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
-template <bool SMALL, int NPAR>
+template <bool SMALL, int NPAR, bool EX = false>
 PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
@@ -1032,7 +1032,8 @@ PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node*
   const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
   f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
   float t = -1.0f;
-  if (!(kAblate && (c.debug & 4))) t = geom_test<-1>(G, ro, rd, pt, nrm);  // cube / sphere decided per lane; shared pre and post parts
+  // cube / sphere decided per lane; shared pre and post parts
+  if (!(kAblate && (c.debug & 4))) t = Ar<EX>::template geom_test<-1, false>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f));
   const uint32_t tb = __float_as_uint(t);
   if (valid && t > 0.f && tb < 0x7f7fffffu) {
     const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
@@ -1050,7 +1051,7 @@ PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node*
 }
 // Append the lanes with `pass` (entry: leaf index, group parity, lane that owns the ray); runs a chunk as soon
 // as 64 entries are pending.  Wave-uniform control flow.
-template <bool SMALL, int NPAR>
+template <bool SMALL, int NPAR, bool EX = false>
 PT_DEV void carry_append(Carry<SMALL, NPAR>& c, bool pass, uint32_t leaf, int par, int owner, int lane,
                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const unsigned long long m = __ballot(pass);
@@ -1063,7 +1064,7 @@ PT_DEV void carry_append(Carry<SMALL, NPAR>& c, bool pass, uint32_t leaf, int pa
   const int cnt = __popcll(m);
   c.count += cnt;
   c.appended += cnt;
-  if (c.count >= 64) carry_chunk(c, 64, lane, nodes, geoms);
+  if (c.count >= 64) carry_chunk<SMALL, NPAR, EX>(c, 64, lane, nodes, geoms);
 }
 // Candidate search of one group (phase 1 of trace_group) feeding the ring.
 // SUB: the scene has subtrees below the top list.  The LDS-table kernels are only used for scenes whose leaves all
@@ -1184,7 +1185,7 @@ PT_DEV int wave_prefix6(int v, int& total) {
 // tested against) for the first n (<= 64) pending records; passing leaves go to the primitive ring.  A leaf that is also
 // listed in the cell the ray came from was handled there: a box occupies a block of cells and the ray's cells inside a
 // block are consecutive.  Wave-uniform control flow.
-template <int NPAR>
+template <int NPAR, bool EX = false>
 PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneTables& sc, int lane,
                         const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
@@ -1198,14 +1199,14 @@ PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneT
   const f3 rd = mk(ray[3 * 64], ray[4 * 64], ray[5 * 64]);
   const float4 NA = reinterpret_cast<const float4*>(sc.grid_items)[2 * item];      // bmin.xyz, bmax.x
   const float4 NB = reinterpret_cast<const float4*>(sc.grid_items)[2 * item + 1];  // bmax.yz, leaf, neighbour bits
-  const RayInv ri = ray_inv(rd, ro);
+  const RayInv ri = Ar<EX>::ray_inv(rd, ro);
   const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + src) + 1]) + sc.cull_margin;
   float tn;
   const bool seen = ((__float_as_uint(NB.w) >> from) & 1u) != 0u;  // from == 7: bit 7 is never set
-  const bool pass = valid && !seen && slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
+  const bool pass = valid && !seen && Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
   cr.head = (cr.head + n) & (kCellRing - 1);
   cr.count -= n;
-  carry_append(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms);
+  carry_append<false, NPAR, EX>(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms);
 }
 // State of a lane's cell walk (3D-DDA): the distance along the ray of the next cell boundary per axis, the distance
 // between boundaries, the cells left before the grid ends, the current cell.
@@ -1263,7 +1264,7 @@ PT_DEV void walk_start(const SceneTables& sc, f3 o, f3 d, float t_from, float t_
 #define PT_GRID_SPLIT 16
 #endif
 constexpr int kGridSplit = PT_GRID_SPLIT;  // lanes still walking when the remaining spans are dealt out (0: never)
-template <int NPAR>
+template <int NPAR, bool EX = false>
 PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& sc, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
   float* rays = c.ray + par * 6 * 64;
@@ -1317,7 +1318,7 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
       // the lanes that filed are a prefix of the lanes (pre grows with the lane index): the last one knows the sum
       const unsigned long long nm = __ballot(now);
       if (nm) cr.count += __builtin_amdgcn_readlane(pre + want, 63 - __builtin_clzll(nm));
-      while (cr.count >= 64) grid_filter(c, cr, 64, sc, lane, nodes, geoms);
+      while (cr.count >= 64) grid_filter<NPAR, EX>(c, cr, 64, sc, lane, nodes, geoms);
     }
     // next cell: through the nearest boundary
     const bool ax = w.tx <= w.ty && w.tx <= w.tz;
@@ -1331,7 +1332,7 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
     else if (ay) w.ty += w.ddy, --w.ly;
     else w.tz += w.ddz, --w.lz;
   }
-  while (cr.count > 0) grid_filter(c, cr, min(64, cr.count), sc, lane, nodes, geoms);
+  while (cr.count > 0) grid_filter<NPAR, EX>(c, cr, min(64, cr.count), sc, lane, nodes, geoms);
 }
 
 // State of a group between its search and its shading (one loop iteration later).
@@ -1388,13 +1389,16 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
 // colour.  That removes the generate launch and ~190 B/sample of HBM round trips (40 B ray state
 // written + 24 B read, 32 B hit record written + read, 28 B path state re-read) at the one depth
 // where every sample is alive.  Also writes the per-queue sample counts of depth 0 (statistics).
-template <bool TABLES_IN_LDS>
+// GRID: large scenes with a uniform grid over the leaf boxes (SceneTables::use_grid): the primary rays walk it like the
+// bounce rays do (grid_search) instead of testing the top list and scanning subtrees; exact arithmetic as in every depth-0 path.
+template <bool TABLES_IN_LDS, bool GRID = false>
 __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
                                                     int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
                                                     ptd::PathBuf out, float4* __restrict__ final_rgba) {
   extern __shared__ float4 lds_raw[];
   char* lds = reinterpret_cast<char*>(lds_raw);
-  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  static_assert(!(GRID && TABLES_IN_LDS), "the grid walk reads the tables from memory");
+  const int nb_top = GRID ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
   stage16(lds + nb_top, sc.mats, nb_mats);
@@ -1411,7 +1415,8 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
     tbl += nb_nodes + nb_geoms;
   }
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveLds);  // after the per-wave blocks
+  constexpr int kWaveBytes = GRID ? carry_bytes<false, 1>() + kCellRing * 4 : kWaveLds;
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);  // after the per-wave blocks
   iter_hash_fill(ihash, sc, b, 0);
   // camera-relative copies for the primary rays: top-list boxes minus the camera position and (tables in LDS only)
   // the camera position in each geom's object space — the same float operations the per-ray code would execute
@@ -1419,7 +1424,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   float* cam_qo = reinterpret_cast<float*>(cam_top + 2 * sc.num_top);
   {
     const f3 cp = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
-    for (int e = threadIdx.x; e < sc.num_top; e += blockDim.x) {
+    for (int e = threadIdx.x; !GRID && e < sc.num_top; e += blockDim.x) {
       const ptd::TopEntry t = sc.top[e];
       cam_top[2 * e] = make_float4(t.bmin[0] - cp.x, t.bmin[1] - cp.y, t.bmin[2] - cp.z, t.bmax[0] - cp.x);
       cam_top[2 * e + 1] = make_float4(t.bmax[1] - cp.y, t.bmax[2] - cp.z, __int_as_float(t.idx), __int_as_float(t.link));
@@ -1432,8 +1437,15 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   __syncthreads();
   const int wib = threadIdx.x >> 6;
   WaveLds w;
-  {
-    char* base = lds + tbl + wib * kWaveLds;
+  Carry<false, 1> cy = carry_init<false, 1>(lds + tbl + wib * kWaveBytes);  // GRID: the bounce kernel's rings
+  CellRing cr{reinterpret_cast<uint32_t*>(lds + tbl + wib * kWaveBytes + carry_bytes<false, 1>()), 0, 0};
+  cy.debug = b.debug;
+  if (GRID) {
+    w.best = cy.best;
+    w.rec = cy.rec;
+    w.list = nullptr;
+  } else {
+    char* base = lds + tbl + wib * kWaveBytes;
     w.best = reinterpret_cast<unsigned long long*>(base);
     w.rec = reinterpret_cast<float*>(base + 64 * 8);
     w.list = reinterpret_cast<uint32_t*>(base + 64 * 8 + 7 * 64 * 4);
@@ -1474,8 +1486,17 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
     const bool near_scene = __ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (near_scene) trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
-    else w.best[lane] = kNoHit;
+    if (GRID) {
+      w.best[lane] = kNoHit;
+      if (near_scene) {
+        grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
+        while (cy.count > 0) carry_chunk<false, 1, kD0>(cy, min(64, cy.count), lane, nodes, geoms);
+      }
+    } else if (near_scene) {
+      trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
+    } else {
+      w.best[lane] = kNoHit;
+    }
     flush_deferred(df, qbase, out);  // the previous chunk's survivors (see Deferred)
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1827,6 +1848,9 @@ int big_lds_bytes(const SceneTables& sc) {
          iter_hash_entries(sc) * 4;
 }
 bool use_big(const SceneTables& sc) { return sc.big_kernel != 0 && !tables_in_lds(sc); }
+int primary_grid_lds_bytes(const SceneTables& sc) {
+  return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * (carry_bytes<false, 1>() + kCellRing * 4) + iter_hash_entries(sc) * 4;
+}
 // The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
 bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
 // Stage the scene tables in LDS only if every leaf is a top-list entry and staging does not cost the dominant kernel a
@@ -1866,7 +1890,8 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false, false>, kBlock, 0);
       break;
     case kPrimary:
-      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
+      if (use_big(sc) && sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false, true>, kBlock, primary_grid_lds_bytes(sc));
+      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kBounce:
@@ -1909,7 +1934,8 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
 
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                     const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float4* final_rgba) {
-  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
+  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
+  else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
 }
 
