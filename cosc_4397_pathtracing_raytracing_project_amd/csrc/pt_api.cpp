@@ -299,10 +299,47 @@ bool build_grid(const std::vector<ptd::Node>& nodes, const float root_min[3], co
     ext[a] = ((double)root_max[a] + 2.0 * pad) - lo[a];
     vol *= ext[a];
   }
-  const double per_len = std::cbrt(density * (double)leaves.size() / vol);
+  // Resolution: about one cell per primitive (density <= 0: a search around that).  What a ray pays is one step per cell
+  // it crosses plus one box test per record it comes across, i.e. per unit length ~ r (cells) and ~ refs * r / ncell
+  // (records), r = mean resolution; measured on the 10 170-primitive scene a record costs about half a step (kernel
+  // time follows refs * r / ncell + 2 r over resolutions 15..31).  The search matters for primitives on a lattice —
+  // the resolution that matches the lattice pitch halves the references — and is harmless otherwise.
+  auto resolution = [&](double per_len, int res[3]) {
+    for (int a = 0; a < 3; ++a) res[a] = (int)std::min(512.0, std::max(1.0, std::floor(ext[a] * per_len + 0.5)));
+  };
+  auto references = [&](const int res[3]) {
+    int64_t refs = 0;
+    for (int li : leaves) {
+      int64_t n = 1;
+      for (int a = 0; a < 3; ++a) {
+        int c0 = (int)std::floor(((double)nodes[li].bmin[a] - pad - lo[a]) / ext[a] * res[a]);
+        int c1 = (int)std::floor(((double)nodes[li].bmax[a] + pad - lo[a]) / ext[a] * res[a]);
+        c0 = std::min(std::max(c0, 0), res[a] - 1);
+        c1 = std::min(std::max(c1, 0), res[a] - 1);
+        n *= c1 - c0 + 1;
+      }
+      refs += n;
+    }
+    return refs;
+  };
+  const double base = std::cbrt((double)leaves.size() / vol);
+  if (density > 0.0) {
+    resolution(std::cbrt(density) * base, gb.res);
+  } else {
+    double best_cost = INFINITY;
+    int last[3] = {0, 0, 0};
+    for (int i = 0; i <= 40; ++i) {
+      int res[3];
+      resolution(base * (0.6 + 0.025 * i), res);
+      if (res[0] == last[0] && res[1] == last[1] && res[2] == last[2]) continue;
+      std::memcpy(last, res, sizeof(last));
+      const double r = (res[0] + res[1] + res[2]) / 3.0, cells = (double)res[0] * res[1] * res[2];
+      const double cost = (double)references(res) * r / cells + 2.0 * r;
+      if (cost < best_cost) best_cost = cost, std::memcpy(gb.res, res, sizeof(res));
+    }
+  }
   int64_t ncell = 1;
   for (int a = 0; a < 3; ++a) {
-    gb.res[a] = (int)std::min(512.0, std::max(1.0, std::floor(ext[a] * per_len + 0.5)));
     gb.gmin[a] = (float)lo[a];
     gb.cs[a] = (float)(ext[a] / gb.res[a]);
     gb.inv_cs[a] = (float)(gb.res[a] / ext[a]);
@@ -649,8 +686,8 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
   if ((g.num_nodes >= kBigKernelNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
     GridBuild gb;
-    const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive
-    if (build_grid(nodes, g.root_min, g.root_max, dens ? atof(dens) : 1.0, (g.debug_flags & 256) != 0, gb)) {
+    const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive instead of the search
+    if (build_grid(nodes, g.root_min, g.root_max, dens ? atof(dens) : 0.0, (g.debug_flags & 256) != 0, gb)) {
       if (dalloc(g, &g.d_grid_start, gb.start.size()) || dalloc(g, &g.d_grid_items, gb.items.size())) return -1;
       HIP_OK(hipMemcpy(g.d_grid_start, gb.start.data(), gb.start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(g.d_grid_items, gb.items.data(), gb.items.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
