@@ -44,6 +44,15 @@ class PtBVHNode(C.Structure):
                 ("geomIndex", C.c_int32)]
 
 
+class PtGridInfo(C.Structure):
+    _fields_ = [("res", C.c_int32 * 3), ("origin", C.c_float * 3), ("cell_size", C.c_float * 3), ("pad", C.c_float),
+                ("num_cells", C.c_int32), ("num_records", C.c_int32), ("num_leaves", C.c_int32)]
+
+
+class PtGridRecord(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("leaf", C.c_int32), ("neighbours", C.c_int32)]
+
+
 class PtSceneDesc(C.Structure):
     _fields_ = [("geoms", C.POINTER(PtGeom)), ("num_geoms", C.c_int32), ("materials", C.POINTER(PtMaterial)),
                 ("num_materials", C.c_int32), ("camera", PtCamera), ("trace_depth", C.c_int32)]
@@ -91,6 +100,7 @@ def lib() -> C.CDLL:
     L.pt_scene_image_name.argtypes = [C.c_void_p]
     L.pt_scene_image_name.restype = C.c_char_p
     L.pt_build_bvh.argtypes = [C.POINTER(PtGeom), C.c_int, C.POINTER(PtBVHNode), C.c_int]
+    L.pt_build_grid.argtypes = [C.POINTER(PtGeom), C.c_int, C.c_int, C.POINTER(PtGridInfo), C.POINTER(C.c_uint32), C.POINTER(PtGridRecord)]
     L.pt_build_transform.argtypes = [_fp, _fp, _fp, _fp]
     L.pt_init.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions)]
     L.pt_render.argtypes = [C.c_int, C.c_int]
@@ -189,6 +199,20 @@ class Scene:
 
     def materials(self):
         return [self.desc.materials[i] for i in range(self.desc.num_materials)]
+
+    def grid(self, forced: bool = False):
+        """The uniform grid over the leaf boxes the renderer would walk (pt_build_grid): (info, cell_start, records) or
+        None when the scene keeps the BVH scan."""
+        info = PtGridInfo()
+        rc = lib().pt_build_grid(self.desc.geoms, self.desc.num_geoms, int(forced), C.byref(info), None, None)
+        if rc < 0:
+            raise PtError(lib().pt_last_error().decode(errors="replace"))
+        if rc == 0:
+            return None
+        start = (C.c_uint32 * (info.num_cells + 1))()
+        recs = (PtGridRecord * info.num_records)()
+        lib().pt_build_grid(self.desc.geoms, self.desc.num_geoms, int(forced), C.byref(info), start, recs)
+        return info, np.frombuffer(start, np.uint32).copy(), recs
 
     def bvh(self):
         n = lib().pt_build_bvh(self.desc.geoms, self.desc.num_geoms, None, 0)

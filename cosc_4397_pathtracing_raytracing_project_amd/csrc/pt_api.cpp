@@ -769,6 +769,29 @@ int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap) {
   return (int)nodes.size();
 }
 
+int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records) {
+  if (!geoms || num_geoms <= 0 || !info) return fail("pt_build_grid: null argument");
+  std::vector<PtBVHNode> ref_nodes;
+  pt::buildBVH(geoms, num_geoms, ref_nodes);
+  std::vector<ptd::Node> nodes;
+  std::vector<int> where(ref_nodes.size(), -1);
+  thread_bvh(ref_nodes, 0, nodes, where);
+  std::memset(info, 0, sizeof(*info));
+  info->num_leaves = num_geoms;
+  if (!forced && (int)nodes.size() < kBigKernelNodes) return 0;
+  GridBuild gb;
+  const char* dens = getenv("PT_GRID_DENSITY");
+  if (!build_grid(nodes, ref_nodes[0].bmin, ref_nodes[0].bmax, dens ? atof(dens) : 0.0, forced != 0, gb)) return 0;
+  for (int a = 0; a < 3; ++a) info->res[a] = gb.res[a], info->origin[a] = gb.gmin[a], info->cell_size[a] = gb.cs[a];
+  info->pad = gb.pad;
+  info->num_cells = (int32_t)(gb.start.size() - 1);
+  info->num_records = (int32_t)gb.items.size();
+  if (cell_start) std::memcpy(cell_start, gb.start.data(), gb.start.size() * sizeof(uint32_t));
+  static_assert(sizeof(PtGridRecord) == sizeof(ptd::Node), "PtGridRecord mirrors the device record");
+  if (records) std::memcpy(records, gb.items.data(), gb.items.size() * sizeof(ptd::Node));
+  return 1;
+}
+
 int pt_build_transform(const float* trs, float* transform, float* inverse, float* invTranspose) {
   if (!trs || !transform || !inverse || !invTranspose) return fail("pt_build_transform: null argument");
   pt::buildTransform(trs, transform, inverse, invTranspose);

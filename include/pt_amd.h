@@ -169,6 +169,26 @@ const char* pt_scene_image_name(const PtScene* s);     /* CAMERA FILE */
  * Returns node count (2n-1); writes up to `cap` nodes if `out` != NULL. */
 int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap);
 
+/* The traversal structure of our own for large scenes (the reference has only the median-split
+ * BVH of pathtrace.cu:52-111): a uniform grid over the leaf boxes, walked by the depth-0 and depth >= 1 kernels instead of
+ * the BVH when the scene has >= 2048 BVH nodes and its primitives are spread evenly enough (at most 12 cell references
+ * per primitive, 32 records per cell; `forced` skips these conditions, as PtOptions.debug_flags 256 does).  The image is
+ * the same either way: a primitive is tested exactly when the ray passes the primitive's own box test, and every leaf is
+ * listed in all cells its box, grown by `pad`, touches.  Host-only (no GPU needed).  Returns 1 and fills `info` when a
+ * grid would be used, 0 when not, -1 on error; cell c's records are records[cell_start[c] .. cell_start[c + 1]),
+ * c = x + res[0] * (y + res[1] * z); either array may be NULL (sizes are in `info`). */
+typedef struct PtGridInfo {
+  int32_t res[3];
+  float origin[3], cell_size[3], pad;
+  int32_t num_cells, num_records, num_leaves;
+} PtGridInfo;
+typedef struct PtGridRecord {
+  float bmin[3], bmax[3]; /* the leaf's box (the reference's worldBounds)                                     */
+  int32_t leaf;           /* index of the leaf in the reference's visiting order (threaded BVH)              */
+  int32_t neighbours;     /* bit a: the leaf is also listed in the neighbour cell -x, +x, -y, +y, -z, +z     */
+} PtGridRecord;
+int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records);
+
 /* transform / inverse / inverse-transpose of an OBJECT block's TRANS ROTAT SCALE
  * (trs[9]), as utilityCore::buildTransformationMatrix + glm::inverse +
  * glm::inverseTranspose compute them (src/utilities.cpp:64-72, src/scene.cpp:83-86). */
