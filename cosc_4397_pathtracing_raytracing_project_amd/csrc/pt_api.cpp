@@ -96,6 +96,9 @@ struct PtContext {
   int grid_res[3] = {0, 0, 0};
   float grid_min[3] = {0, 0, 0}, grid_cs[3] = {0, 0, 0}, grid_inv_cs[3] = {0, 0, 0}, grid_pad = 0.f;
   bool have_grid = false;
+  bool grid_enabled = true;      // the outcome of choose_traversal()
+  float probe_ms[2] = {0.f, 0.f};  // one iteration with the BVH scan / with the grid, as timed by choose_traversal()
+  int cap_bpc = 8;
   bool legacy = false;
   int debug_flags = 0;
   bool fuse_primary = true, fuse_bounces = true;
@@ -361,8 +364,8 @@ bool build_grid(const std::vector<ptd::Node>& nodes, const float root_min[3], co
     refs += (int64_t)(c1[0] - c0[0] + 1) * (c1[1] - c0[1] + 1) * (c1[2] - c0[2] + 1);
     if (refs > (int64_t)1 << 22) return false;  // ring entries hold 22-bit record indices
   }
-  // worth it only for evenly spread primitives of similar size: few cells per leaf, short lists per cell
-  if (!forced && refs > 12 * (int64_t)leaves.size()) return false;
+  // a candidate only while the lists stay moderate (whether it beats the BVH scan is measured, choose_traversal())
+  if (!forced && refs > 64 * (int64_t)leaves.size()) return false;
   for (int li : leaves) {
     int c0[3], c1[3];
     for (int a = 0; a < 3; ++a) cell_range(nodes[li], a, c0[a], c1[a]);
@@ -376,7 +379,7 @@ bool build_grid(const std::vector<ptd::Node>& nodes, const float root_min[3], co
     gb.start[c + 1] = gb.start[c] + count[c];
     longest = std::max(longest, count[c]);
   }
-  if (!forced && longest > 32) return false;
+  if (!forced && longest > 4096) return false;
   gb.items.assign((size_t)refs, ptd::Node{});
   std::vector<uint32_t> fill(gb.start.begin(), gb.start.end() - 1);
   for (int li : leaves) {  // threaded (= reference visiting) order inside every cell
@@ -415,7 +418,7 @@ ptk::SceneTables tables(const Ctx& g) {
   // k_bounce_big from kBigKernelNodes nodes on; debug_flags 64 / 128 force k_bounce<false> / k_bounce_big (A/B, same results)
   t.big_kernel = (g.debug_flags & 64) ? 0 : ((g.debug_flags & 128) ? 1 : (g.num_nodes >= kBigKernelNodes ? 1 : 0));
   // the grid walk lives in the big kernel; debug_flags 256 builds and uses it for any scene, 512 never (A/B, same results)
-  t.use_grid = g.have_grid && !(g.debug_flags & 512) && !(g.debug_flags & 64) ? 1 : 0;
+  t.use_grid = g.have_grid && g.grid_enabled && !(g.debug_flags & 512) && !(g.debug_flags & 64) ? 1 : 0;
   if (t.use_grid) {
     t.big_kernel = 1;
     t.lds_table_bytes = -1;  // (a forced grid on a small scene: the big kernel reads the tables from memory)
@@ -506,6 +509,47 @@ int run_batch(Ctx& g, int iter_first, int kb) {
     HIP_OK(hipStreamSynchronize(g.stream));
     if (resolve_events(g)) return -1;
   }
+  return 0;
+}
+
+// Launch geometry (persistent grids = resident workgroups) for the kernels the current tables select.
+void plan_launch(Ctx& g) {
+  const char* kb = getenv("PT_LDS_TABLE_KB");  // test / experiment knob: force the LDS staging limit of the scene tables
+  g.lds_table_bytes = g.k->lds_table_limit(tables(g), kb ? atoi(kb) * 1024 : -1);
+  const ptk::SceneTables t = tables(g);
+  g.grid_gen = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kGenerate, t));
+  g.grid_isect = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
+  g.grid_shade = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kShade, t));
+  g.grid_primary = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
+  g.grid_bounce = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounce, t));
+}
+
+// Grid or BVH scan?  Both give the same image; which is faster depends on how the primitives are
+// spread and how far rays fly, and no count of references predicted it across lattice, random and clustered scenes — so
+// it is measured: up to 8 iterations of the context's own tile with each (the second of two runs counts), before the
+// first sample is rendered.  Costs a few tens of milliseconds for a 1080p tile.  debug_flags 256 / 512 skip the measurement.
+int choose_traversal(Ctx& g) {
+  if (!g.have_grid || !g.fuse_bounces || (g.debug_flags & (256 | 512 | 64))) return 0;
+  for (int v = 0; v < 2; ++v) {
+    g.grid_enabled = v == 1;
+    plan_launch(g);
+    for (int rep = 0; rep < 2; ++rep) {
+      EventPair ev{};
+      if (get_events(g, &ev)) return -1;
+      HIP_OK(hipEventRecord(ev.a, g.stream));
+      if (run_batch(g, 1, std::min(g.K, 8))) return -1;  // enough groups per wave for the persistent grids to fill
+      HIP_OK(hipEventRecord(ev.b, g.stream));
+      HIP_OK(hipStreamSynchronize(g.stream));
+      HIP_OK(hipEventElapsedTime(&g.probe_ms[v], ev.a, ev.b));
+      g.free_events.push_back(ev);
+    }
+  }
+  g.grid_enabled = g.probe_ms[1] < g.probe_ms[0];
+  plan_launch(g);
+  HIP_OK(hipMemsetAsync(g.d_image, 0, 3 * (size_t)g.N * sizeof(float), g.stream));
+  HIP_OK(hipMemsetAsync(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long), g.stream));
+  HIP_OK(hipStreamSynchronize(g.stream));
+  g.samples = 0;
   return 0;
 }
 
@@ -698,17 +742,8 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
     }
   }
 
-  {
-    const char* kb = getenv("PT_LDS_TABLE_KB");  // test / experiment knob: force the LDS staging limit of the scene tables
-    g.lds_table_bytes = g.k->lds_table_limit(tables(g), kb ? atoi(kb) * 1024 : -1);
-    const ptk::SceneTables t = tables(g);
-    const int cap_bpc = opt.blocks_per_cu > 0 ? std::min(opt.blocks_per_cu, 8) : 8;
-    g.grid_gen = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kGenerate, t));
-    g.grid_isect = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
-    g.grid_shade = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kShade, t));
-    g.grid_primary = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
-    g.grid_bounce = g.num_cus * std::min(cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounce, t));
-  }
+  g.cap_bpc = opt.blocks_per_cu > 0 ? std::min(opt.blocks_per_cu, 8) : 8;
+  plan_launch(g);
   // path state
   if (alloc_pathbuf(g, &g.buf[0], g.stride) || alloc_pathbuf(g, &g.buf[1], g.stride)) return -1;
   if (!g.fuse_bounces && alloc_hitbuf(g, &g.hits, g.stride)) return -1;  // hit records reach HBM only in the unfused form
@@ -718,8 +753,9 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   if (dalloc(g, &g.d_stats, PT_MAX_DEPTH)) return -1;
   HIP_OK(hipMemset(g.d_image, 0, 3 * (size_t)g.N * sizeof(float)));
   HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));
-  g.time_kernels = opt.time_kernels != 0;
   HIP_OK(hipDeviceSynchronize());
+  if (choose_traversal(g)) return -1;
+  g.time_kernels = opt.time_kernels != 0;
   return 0;
 }
 

@@ -99,8 +99,8 @@ typedef struct PtOptions {
   int32_t debug_flags;      /* A-B switches with UNCHANGED results: 16 no closer-hit cull in the subtree scans, 32 no
                                near-first subtree order, 64 / 128 force the pipelined / the high-occupancy depth >= 1
                                kernel for scenes whose tables are not in LDS (default: by BVH size), 256 / 512 force /
-                               forbid the uniform-grid walk of the depth >= 1 kernel (default: large scenes whose
-                               primitives are evenly spread).  Bits 0-3 are profiling ablations with WRONG results
+                               forbid the uniform-grid walk of the fused kernels (default: for large scenes, whichever of
+                               grid and BVH scan renders one iteration faster at pt_init).  Bits 0-3 are profiling ablations with WRONG results
                                (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
                                they exist only in -DPT_ABLATE builds of the library (tools/pmc_ablate.sh) and
                                pt_init fails on them otherwise (pt_library_has_ablations()).  (Environment,
@@ -171,12 +171,14 @@ int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap);
 
 /* The traversal structure of our own for large scenes (the reference has only the median-split
  * BVH of pathtrace.cu:52-111): a uniform grid over the leaf boxes, walked by the depth-0 and depth >= 1 kernels instead of
- * the BVH when the scene has >= 2048 BVH nodes and its primitives are spread evenly enough (at most 12 cell references
- * per primitive, 32 records per cell; `forced` skips these conditions, as PtOptions.debug_flags 256 does).  The image is
- * the same either way: a primitive is tested exactly when the ray passes the primitive's own box test, and every leaf is
- * listed in all cells its box, grown by `pad`, touches.  Host-only (no GPU needed).  Returns 1 and fills `info` when a
- * grid would be used, 0 when not, -1 on error; cell c's records are records[cell_start[c] .. cell_start[c + 1]),
- * c = x + res[0] * (y + res[1] * z); either array may be NULL (sizes are in `info`). */
+ * the BVH.  The image is the same either way: a primitive is tested exactly when the ray passes the primitive's own box
+ * test, and every leaf is listed in all cells its box, grown by `pad`, touches.  A scene is a CANDIDATE when it has
+ * >= 2048 BVH nodes and its lists stay moderate (at most 64 cell references per primitive; `forced` skips both
+ * conditions, as PtOptions.debug_flags 256 does); for a candidate pt_init / pt_ctx_create time one iteration of the
+ * tile with the grid and one with the BVH scan and keep the faster (PtStats.grid_cells > 0: the grid).  This function is
+ * host-only (no GPU needed).  Returns 1 and fills `info` for a candidate, 0 otherwise, -1 on error; cell c's records
+ * are records[cell_start[c] .. cell_start[c + 1]), c = x + res[0] * (y + res[1] * z); either array may be NULL (sizes
+ * are in `info`). */
 typedef struct PtGridInfo {
   int32_t res[3];
   float origin[3], cell_size[3], pad;

@@ -161,7 +161,7 @@ def test_grid_lists_every_leaf_in_every_cell_its_box_touches(test_scenes, name):
         assert (np.diff(seg) > 0).all()
 
 
-def test_grid_is_chosen_for_large_even_scenes_only(tmp_path):
+def test_grid_candidates(tmp_path):
     even = capi.Scene(scenes.write_scene(scenes.stress_scene_text((12, 12, 10), res=(96, 64)), str(tmp_path / "e.txt")))
     assert len(even.bvh()) >= 2048
     info, start, recs = even.grid()
@@ -170,5 +170,5 @@ def test_grid_is_chosen_for_large_even_scenes_only(tmp_path):
     clustered = capi.Scene(scenes.write_scene(scenes.random_scene_text(6, 1500, res=(96, 64), clustered=True), str(tmp_path / "c.txt")))
     assert len(clustered.bvh()) >= 2048
     g = clustered.grid()
-    if g is not None:  # accepted only within the bounds the builder promises
-        assert g[0].num_records <= 12 * g[0].num_leaves and np.diff(g[1].astype(np.int64)).max() <= 32
+    if g is not None:  # a candidate only within the bound the builder promises (the renderer then measures both)
+        assert g[0].num_records <= 64 * g[0].num_leaves

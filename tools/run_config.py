@@ -27,7 +27,7 @@ def run(scene="stress", res=(1920, 1080), spp=100, depth=8, grid=(22, 22, 21), a
     live = np.array(st.live_rays[:depth], float)
     out = {"metric": f"Msamples/s, {scene} {w}x{h} depth {depth}", "value": round(w * h * spp / dt / 1e6, 2), "unit": "Msamples/s",
            "config": {"workload": f"{scene}: {sc.desc.num_geoms} primitives, {len(sc.bvh())} BVH nodes, {w}x{h}, {spp} spp, depth {depth}",
-                      "arith": arith, "iters_per_batch": int(st.iters_per_batch), "device_mem_mb": round(st.device_bytes / 2 ** 20)},
+                      "arith": arith, "traversal": f"uniform grid, {int(st.grid_cells)} cells" if st.grid_cells else "bvh", "iters_per_batch": int(st.iters_per_batch), "device_mem_mb": round(st.device_bytes / 2 ** 20)},
            "seconds": round(dt, 4), "live_rays_per_sample": round(float(live.sum() / st.samples), 4),
            "alive_by_depth": np.round(live / st.samples, 4).tolist(),
            "dominant_kernel_us": round(st.intersect_ms / max(1, st.intersect_launches) * 1e3, 1), "dominant_kernel_launches": int(st.intersect_launches),
