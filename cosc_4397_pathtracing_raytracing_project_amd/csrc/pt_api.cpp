@@ -32,6 +32,7 @@ constexpr bool kAblateBuild = false;  // release library: pt_init rejects them
 #endif
 
 std::string g_err;
+constexpr int kGridNodes = 1024;       // scenes from this many BVH nodes on are candidates for the uniform grid (build_grid, choose_traversal)
 constexpr int kBigKernelNodes = 2048;  // see tables(): scenes from this many BVH nodes on run depths >= 1 in k_bounce_big
 }  // namespace
 int pt_fail(const char* fmt, ...) {  // pt_internal.h: sets pt_last_error(), returns -1
@@ -728,7 +729,7 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
-  if ((g.num_nodes >= kBigKernelNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
+  if ((g.num_nodes >= kGridNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
     GridBuild gb;
     const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive instead of the search
     if (build_grid(nodes, g.root_min, g.root_max, dens ? atof(dens) : 0.0, (g.debug_flags & 256) != 0, gb)) {
@@ -814,7 +815,7 @@ int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* in
   thread_bvh(ref_nodes, 0, nodes, where);
   std::memset(info, 0, sizeof(*info));
   info->num_leaves = num_geoms;
-  if (!forced && (int)nodes.size() < kBigKernelNodes) return 0;
+  if (!forced && (int)nodes.size() < kGridNodes) return 0;
   GridBuild gb;
   const char* dens = getenv("PT_GRID_DENSITY");
   if (!build_grid(nodes, ref_nodes[0].bmin, ref_nodes[0].bmax, dens ? atof(dens) : 0.0, forced != 0, gb)) return 0;

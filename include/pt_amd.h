@@ -173,7 +173,7 @@ int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap);
  * BVH of pathtrace.cu:52-111): a uniform grid over the leaf boxes, walked by the depth-0 and depth >= 1 kernels instead of
  * the BVH.  The image is the same either way: a primitive is tested exactly when the ray passes the primitive's own box
  * test, and every leaf is listed in all cells its box, grown by `pad`, touches.  A scene is a CANDIDATE when it has
- * >= 2048 BVH nodes and its lists stay moderate (at most 64 cell references per primitive; `forced` skips both
+ * >= 1024 BVH nodes and its lists stay moderate (at most 64 cell references per primitive; `forced` skips both
  * conditions, as PtOptions.debug_flags 256 does); for a candidate pt_init / pt_ctx_create time one iteration of the
  * tile with the grid and one with the BVH scan and keep the faster (PtStats.grid_cells > 0: the grid).  This function is
  * host-only (no GPU needed).  Returns 1 and fills `info` for a candidate, 0 otherwise, -1 on error; cell c's records

@@ -81,7 +81,11 @@ def test_image_bit_exact_vs_oracle(scene_dir, oracle, scene, res, spp, depth, kw
     diff = (bits(img) != bits(ref)).any(axis=1)
     assert not diff.any(), f"{diff.sum()} pixels differ, first {np.flatnonzero(diff)[:8]}"
     assert st.samples == res[0] * res[1] * spp
-    assert (st.grid_cells > 0) == bool(kw.get("debug_flags", 0) & 256)
+    flags = kw.get("debug_flags", 0)  # without 256 / 512 a large scene's structure is whichever rendered the probe faster
+    if flags & 256:
+        assert st.grid_cells > 0
+    if flags & 512 or scene in ("cornell", "sphere"):
+        assert st.grid_cells == 0
 
 
 @pytest.mark.parametrize("kw", [{}, dict(unfused_bounces=True), dict(unfused_primary=True)])
