@@ -84,7 +84,7 @@ def test_image_bit_exact_vs_oracle(scene_dir, oracle, scene, res, spp, depth, kw
     flags = kw.get("debug_flags", 0)  # without 256 / 512 a large scene's structure is whichever rendered the probe faster
     if flags & 256:
         assert st.grid_cells > 0
-    if flags & 512 or scene in ("cornell", "sphere"):
+    elif flags & 512 or scene in ("cornell", "sphere"):
         assert st.grid_cells == 0
 
 
