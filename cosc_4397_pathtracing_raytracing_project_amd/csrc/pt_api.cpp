@@ -287,7 +287,7 @@ struct GridBuild {
   std::vector<uint32_t> start;
   std::vector<ptd::Node> items;
 };
-bool build_grid(const std::vector<ptd::Node>& nodes, const float root_min[3], const float root_max[3], double density,
+bool build_grid(const std::vector<ptd::Node>& nodes, const std::vector<PtGeom>& geoms, const float root_min[3], const float root_max[3], double density,
                 bool forced, GridBuild& gb) {
   std::vector<int> leaves;
   for (size_t i = 0; i < nodes.size(); ++i)
@@ -365,6 +365,7 @@ bool build_grid(const std::vector<ptd::Node>& nodes, const float root_min[3], co
     refs += (int64_t)(c1[0] - c0[0] + 1) * (c1[1] - c0[1] + 1) * (c1[2] - c0[2] + 1);
     if (refs > (int64_t)1 << 22) return false;  // ring entries hold 22-bit record indices
   }
+  if (geoms.size() > ((size_t)1 << 24)) return false;  // records hold 24-bit geom indices
   // a candidate only while the lists stay moderate (whether it beats the BVH scan is measured, choose_traversal())
   if (!forced && refs > 64 * (int64_t)leaves.size()) return false;
   for (int li : leaves) {
@@ -392,7 +393,7 @@ bool build_grid(const std::vector<ptd::Node>& nodes, const float root_min[3], co
           ptd::Node it = nodes[li];
           it.skip = li;
           it.geom = (x > c0[0] ? 1 : 0) | (x < c1[0] ? 2 : 0) | (y > c0[1] ? 4 : 0) | (y < c1[1] ? 8 : 0) | (z > c0[2] ? 16 : 0) |
-                    (z < c1[2] ? 32 : 0);
+                    (z < c1[2] ? 32 : 0) | ((geoms[nodes[li].geom].type & 3) << 6) | (nodes[li].geom << 8);
           gb.items[fill[(size_t)x + (size_t)gb.res[0] * ((size_t)y + (size_t)gb.res[1] * z)]++] = it;
         }
   }
@@ -732,7 +733,7 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   if ((g.num_nodes >= kGridNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
     GridBuild gb;
     const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive instead of the search
-    if (build_grid(nodes, g.root_min, g.root_max, dens ? atof(dens) : 0.0, (g.debug_flags & 256) != 0, gb)) {
+    if (build_grid(nodes, g.geoms, g.root_min, g.root_max, dens ? atof(dens) : 0.0, (g.debug_flags & 256) != 0, gb)) {
       if (dalloc(g, &g.d_grid_start, gb.start.size()) || dalloc(g, &g.d_grid_items, gb.items.size())) return -1;
       HIP_OK(hipMemcpy(g.d_grid_start, gb.start.data(), gb.start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(g.d_grid_items, gb.items.data(), gb.items.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
@@ -818,7 +819,7 @@ int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* in
   if (!forced && (int)nodes.size() < kGridNodes) return 0;
   GridBuild gb;
   const char* dens = getenv("PT_GRID_DENSITY");
-  if (!build_grid(nodes, ref_nodes[0].bmin, ref_nodes[0].bmax, dens ? atof(dens) : 0.0, forced != 0, gb)) return 0;
+  if (!build_grid(nodes, std::vector<PtGeom>(geoms, geoms + num_geoms), ref_nodes[0].bmin, ref_nodes[0].bmax, dens ? atof(dens) : 0.0, forced != 0, gb)) return 0;
   for (int a = 0; a < 3; ++a) info->res[a] = gb.res[a], info->origin[a] = gb.gmin[a], info->cell_size[a] = gb.cs[a];
   info->pad = gb.pad;
   info->num_cells = (int32_t)(gb.start.size() - 1);

@@ -181,10 +181,13 @@ struct Ar {
   static PT_DEV bool slab_t(f3 o, const RayInv& ri, float a, float b, float c, float d, float e, float f, float& tn) {
     if constexpr (EX) return ex::slab_t(o, ri, a, b, c, d, e, f, tn); else return md::slab_t(o, ri, a, b, c, d, e, f, tn);
   }
-  template <int TYPE, bool QO>
-  static PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro, f3 rd, f3& point, f3& normal, f3 qo_pre) {
-    if constexpr (EX) return ex::geom_test<TYPE, QO>(G, ro, rd, point, normal, qo_pre);
-    else return md::geom_test<TYPE, QO>(G, ro, rd, point, normal, qo_pre);
+  template <int TYPE, bool QO, bool DEFER = false>
+  static PT_DEV float geom_test(const ptd::Geom* __restrict__ G, f3 ro, f3 rd, f3& point, f3& normal, f3 qo_pre, int rt_type = -1) {
+    if constexpr (EX) return ex::geom_test<TYPE, QO, DEFER>(G, ro, rd, point, normal, qo_pre, rt_type);
+    else return md::geom_test<TYPE, QO, DEFER>(G, ro, rd, point, normal, qo_pre, rt_type);
+  }
+  static PT_DEV f3 finish_normal(const ptd::Geom* __restrict__ G, f3 stored) {
+    if constexpr (EX) return ex::finish_normal(G, stored); else return md::finish_normal(G, stored);
   }
   static PT_DEV f3 camera_dir(const ptd::Camera& cam, float inv_w, int p, bool aa, float jx, float jy) {
     if constexpr (EX) return ex::camera_dir(cam, inv_w, p, aa, jx, jy); else return md::camera_dir(cam, inv_w, p, aa, jx, jy);
@@ -996,6 +999,7 @@ struct Carry {
   Ent* ent;                  // [kRing]     (leaf << 7) | (parity << 6) | owner lane
   float* ray;                // [2][6][64]  origin xyz, direction xyz of each lane's ray, by group parity
   int* slot;                 // [64]        scratch of the work-stealing step (carry_search); not SMALL only
+  uint32_t* gix;             // [kRing]     LEAN chunks (grid walk) only: geom index | primitive type << 30 of each ring entry
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
   int debug;                 // BatchInfo::debug
@@ -1014,10 +1018,14 @@ PT_DEV Carry<SMALL, NPAR> carry_init(char* base) {
   c.slot = reinterpret_cast<int*>(base + NPAR * 64 * 8 + 2 * NPAR * 6 * 64 * 4 + kRing * 4);
   c.head = c.count = c.appended = c.processed = 0;
   c.debug = 0;
+  c.gix = nullptr;
   return c;
 }
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
-template <bool SMALL, int NPAR, bool EX = false>
+// LEAN (the grid walk): the geom index and primitive type come with the ring entry (Carry::gix) instead of through
+// nodes[leaf] and the geom record, and the world-space normal is computed for the winner only (finish_normal): 6
+// 16-byte reads per candidate instead of 9 (cube) or 11 (sphere) — the L1's access rate is what bounds those kernels.
+template <bool SMALL, int NPAR, bool EX = false, bool LEAN = false>
 PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
@@ -1029,11 +1037,15 @@ PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node*
   const float* ray = c.ray + par * 6 * 64 + src;
   const f3 ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
   const f3 rd = mk(ray[3 * 64], ray[4 * 64], ray[5 * 64]);
-  const ptd::Geom* G = geoms + (valid ? nodes[leaf].geom : 0);
+  const uint32_t gw = LEAN ? c.gix[idx] : 0u;
+  const ptd::Geom* G = geoms + (valid ? (LEAN ? (int)(gw & 0x3fffffffu) : nodes[leaf].geom) : 0);
   f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
   float t = -1.0f;
   // cube / sphere decided per lane; shared pre and post parts
-  if (!(kAblate && (c.debug & 4))) t = Ar<EX>::template geom_test<-1, false>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f));
+  if (!(kAblate && (c.debug & 4))) {
+    if (LEAN) t = Ar<EX>::template geom_test<-1, false, true>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f), valid ? (int)(gw >> 30) : 0);
+    else t = Ar<EX>::template geom_test<-1, false>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f));
+  }
   const uint32_t tb = __float_as_uint(t);
   if (valid && t > 0.f && tb < 0x7f7fffffu) {
     const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
@@ -1051,20 +1063,21 @@ PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node*
 }
 // Append the lanes with `pass` (entry: leaf index, group parity, lane that owns the ray); runs a chunk as soon
 // as 64 entries are pending.  Wave-uniform control flow.
-template <bool SMALL, int NPAR, bool EX = false>
+template <bool SMALL, int NPAR, bool EX = false, bool LEAN = false>
 PT_DEV void carry_append(Carry<SMALL, NPAR>& c, bool pass, uint32_t leaf, int par, int owner, int lane,
-                         const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
+                         const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, uint32_t gword = 0u) {
   const unsigned long long m = __ballot(pass);
   if (!m) return;
   const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   if (pass) {
     const int idx = (c.head + c.count + rank) & (kRing - 1);
     c.ent[idx] = (typename Carry<SMALL, NPAR>::Ent)((leaf << 7) | ((uint32_t)par << 6) | (uint32_t)owner);
+    if (LEAN) c.gix[idx] = gword;
   }
   const int cnt = __popcll(m);
   c.count += cnt;
   c.appended += cnt;
-  if (c.count >= 64) carry_chunk<SMALL, NPAR, EX>(c, 64, lane, nodes, geoms);
+  if (c.count >= 64) carry_chunk<SMALL, NPAR, EX, LEAN>(c, 64, lane, nodes, geoms);
 }
 // Candidate search of one group (phase 1 of trace_group) feeding the ring.
 // SUB: the scene has subtrees below the top list.  The LDS-table kernels are only used for scenes whose leaves all
@@ -1169,6 +1182,7 @@ struct CellRing {
   uint32_t* ent;  // [kCellRing]
   int head, count;
 };
+constexpr int kGridWaveBytes = carry_bytes<false, 1>() + kCellRing * 4 + kRing * 4;  // Carry + cell ring + Carry::gix per wave
 // Exclusive prefix sum over the wave of a small count (< 64) per lane, and the total: one ballot per bit.
 PT_DEV int wave_prefix6(int v, int& total) {
   int pre = 0;
@@ -1202,11 +1216,13 @@ PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneT
   const RayInv ri = Ar<EX>::ray_inv(rd, ro);
   const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + src) + 1]) + sc.cull_margin;
   float tn;
-  const bool seen = ((__float_as_uint(NB.w) >> from) & 1u) != 0u;  // from == 7: bit 7 is never set
+  const uint32_t bits = __float_as_uint(NB.w);  // neighbour bits | primitive type << 6 | geom index << 8
+  const bool seen = ((bits & 63u) >> from) & 1u;  // from == 7: first cell of a walk, nothing seen
   const bool pass = valid && !seen && Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
   cr.head = (cr.head + n) & (kCellRing - 1);
   cr.count -= n;
-  carry_append<false, NPAR, EX>(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms);
+  carry_append<false, NPAR, EX, true>(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms,
+                                      (bits >> 8) | (((bits >> 6) & 3u) << 30));
 }
 // State of a lane's cell walk (3D-DDA): the distance along the ray of the next cell boundary per axis, the distance
 // between boundaries, the cells left before the grid ends, the current cell.
@@ -1415,7 +1431,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
     tbl += nb_nodes + nb_geoms;
   }
-  constexpr int kWaveBytes = GRID ? carry_bytes<false, 1>() + kCellRing * 4 : kWaveLds;
+  constexpr int kWaveBytes = GRID ? kGridWaveBytes : kWaveLds;
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);  // after the per-wave blocks
   iter_hash_fill(ihash, sc, b, 0);
   // camera-relative copies for the primary rays: top-list boxes minus the camera position and (tables in LDS only)
@@ -1441,6 +1457,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   CellRing cr{reinterpret_cast<uint32_t*>(lds + tbl + wib * kWaveBytes + carry_bytes<false, 1>()), 0, 0};
   cy.debug = b.debug;
   if (GRID) {
+    cy.gix = cr.ent + kCellRing;
     w.best = cy.best;
     w.rec = cy.rec;
     w.list = nullptr;
@@ -1490,7 +1507,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
       w.best[lane] = kNoHit;
       if (near_scene) {
         grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
-        while (cy.count > 0) carry_chunk<false, 1, kD0>(cy, min(64, cy.count), lane, nodes, geoms);
+        while (cy.count > 0) carry_chunk<false, 1, kD0, true>(cy, min(64, cy.count), lane, nodes, geoms);
       }
     } else if (near_scene) {
       trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
@@ -1513,9 +1530,11 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
       int hmat = 0;
       if (hit) {
         ht = __uint_as_float((uint32_t)(best >> 32));
-        hmat = geoms[nodes[(uint32_t)best].geom].material;
+        const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
+        hmat = G->material;
         hn = mk(w.rec[0 * 64 + lane], w.rec[1 * 64 + lane], w.rec[2 * 64 + lane]);
         hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
+        if (GRID) hn = Ar<kD0>::finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k), p, ht, hmat, s);
     }
@@ -1658,13 +1677,14 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const ptd::Node* nodes = sc.nodes;
   const ptd::Geom* geoms = sc.geoms;
   const int tbl = nb_top + nb_mats;
-  constexpr int kWaveBytes = carry_bytes<false, 1>() + (GRID ? kCellRing * 4 : 0);
+  constexpr int kWaveBytes = GRID ? kGridWaveBytes : carry_bytes<false, 1>();
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);
   iter_hash_fill(ihash, sc, b, depth);
   __syncthreads();
   const int wib = threadIdx.x >> 6;
   Carry<false, 1> cy = carry_init<false, 1>(lds + tbl + wib * kWaveBytes);
   CellRing cr{reinterpret_cast<uint32_t*>(lds + tbl + wib * kWaveBytes + carry_bytes<false, 1>()), 0, 0};
+  if (GRID) cy.gix = cr.ent + kCellRing;
   cy.debug = b.debug;
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
@@ -1687,7 +1707,7 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
       if (GRID) grid_search<1>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
       else carry_search<true, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
     }
-    while (cy.count > 0) carry_chunk(cy, min(64, cy.count), lane, nodes, geoms);
+    while (cy.count > 0) carry_chunk<false, 1, false, GRID>(cy, min(64, cy.count), lane, nodes, geoms);
     // shade: direction from the wave's LDS ray buffer, colour and slot from memory
     ShadeIO s;
     s.o = mk(0.f, 0.f, 0.f);
@@ -1705,9 +1725,11 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
       int hmat = 0;
       if (hit) {
         ht = __uint_as_float((uint32_t)(best >> 32));
-        hmat = geoms[nodes[(uint32_t)best].geom].material;
+        const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
+        hmat = G->material;
         hn = mk(cy.rec[0 * 64 + lane], cy.rec[1 * 64 + lane], cy.rec[2 * 64 + lane]);
         hp = mk(cy.rec[3 * 64 + lane], cy.rec[4 * 64 + lane], cy.rec[5 * 64 + lane]);
+        if (GRID) hn = finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
       }
       int k, p;
       divmod(slot, b.N, inv_n, k, p);
@@ -1843,13 +1865,13 @@ int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
 int big_lds_bytes(const SceneTables& sc) {
   if (sc.use_grid)
-    return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * (carry_bytes<false, 1>() + kCellRing * 4) + iter_hash_entries(sc) * 4;
+    return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * kGridWaveBytes + iter_hash_entries(sc) * 4;
   return sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * carry_bytes<false, 1>() +
          iter_hash_entries(sc) * 4;
 }
 bool use_big(const SceneTables& sc) { return sc.big_kernel != 0 && !tables_in_lds(sc); }
 int primary_grid_lds_bytes(const SceneTables& sc) {
-  return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * (carry_bytes<false, 1>() + kCellRing * 4) + iter_hash_entries(sc) * 4;
+  return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * kGridWaveBytes + iter_hash_entries(sc) * 4;
 }
 // The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
 bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }

@@ -187,7 +187,8 @@ typedef struct PtGridInfo {
 typedef struct PtGridRecord {
   float bmin[3], bmax[3]; /* the leaf's box (the reference's worldBounds)                                     */
   int32_t leaf;           /* index of the leaf in the reference's visiting order (threaded BVH)              */
-  int32_t neighbours;     /* bit a: the leaf is also listed in the neighbour cell -x, +x, -y, +y, -z, +z     */
+  int32_t neighbours;     /* bits 0-5: the leaf is also listed in the neighbour cell -x, +x, -y, +y, -z, +z;
+                             bits 6-7: primitive type; bits 8-31: index of the primitive in PtSceneDesc.geoms  */
 } PtGridRecord;
 int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records);
 

@@ -117,6 +117,10 @@ def test_grid_lists_every_leaf_in_every_cell_its_box_touches(test_scenes, name):
     # the grid covers the tree's bounds with room to spare
     assert (origin < bmin[0] - info.pad).all() and (origin + cs * res > bmax[0] + info.pad).all()
     rb = np.array([[r.bmin[0], r.bmin[1], r.bmin[2], r.bmax[0], r.bmax[1], r.bmax[2]] for r in recs], F)
+    gtype = np.array([g.type for g in sc.geoms()])
+    gbox = np.zeros((len(gtype), 6), F)  # leaf box of every primitive, from the reference tree
+    for i in np.flatnonzero(geom >= 0):
+        gbox[geom[i]] = np.concatenate([bmin[i], bmax[i]])
     rleaf = np.array([r.leaf for r in recs])
     rbits = np.array([r.neighbours for r in recs])
     cell_of = np.repeat(np.arange(info.num_cells), np.diff(start.astype(np.int64)))
@@ -155,7 +159,9 @@ def test_grid_lists_every_leaf_in_every_cell_its_box_touches(test_scenes, name):
             inside = 0 <= nx < res[0] and 0 <= ny < res[1] and 0 <= nz < res[2]
             listed = inside and (nx + res[0] * (ny + res[1] * nz)) in members[int(rleaf[k])]
             assert bool((rbits[k] >> a) & 1) == listed
-        assert rbits[k] >> 6 == 0
+        gi = rbits[k] >> 8  # the primitive behind the leaf and its type ride along (one fetch less per candidate)
+        assert (rbits[k] >> 6) & 3 == gtype[gi]
+        assert np.array_equal(rb[k].view(np.uint32), gbox[gi].view(np.uint32))
     # records of a cell are in the reference's visiting order
     for c in range(0, info.num_cells, max(1, info.num_cells // 500)):
         seg = rleaf[start[c]:start[c + 1]]
