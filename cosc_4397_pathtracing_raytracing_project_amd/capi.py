@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
     L.pt_write_png_rgb8.argtypes = [C.c_char_p, _u8p, C.c_int, C.c_int]
     L.pt_output_basename.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     L.pt_save_png.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
+    L.pt_save_hdr.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
     L.pt_save_pfm.argtypes = [C.c_char_p, _fp, C.c_int, C.c_int, C.c_float]
     _lib = L
     return L
@@ -405,6 +406,13 @@ def output_basename(name: str, samples: int) -> str:
 def save_png(path: str, rgb_sum: np.ndarray, w: int, h: int, samples: float) -> None:
     a = np.ascontiguousarray(rgb_sum, np.float32)
     if lib().pt_save_png(os.fsencode(path), _f(a), w, h, C.c_float(samples)) != 0:
+        raise PtError(f"cannot write {path}")
+
+
+def save_hdr(path: str, rgb_sum: np.ndarray, w: int, h: int, samples: float) -> None:
+    """image::saveHDR's Radiance file (x mirrored, sum / samples), byte for byte the reference writer's."""
+    a = np.ascontiguousarray(rgb_sum, np.float32)
+    if lib().pt_save_hdr(os.fsencode(path), _f(a), w, h, C.c_float(samples)) != 0:
         raise PtError(f"cannot write {path}")
 
 

@@ -2,6 +2,7 @@
 // saveImage() (src/main.cpp:86-107) + image::savePNG (src/image.cpp:22-39) produce,
 // without stb: a self-contained PNG encoder (zlib "stored" deflate blocks) and a
 // PFM writer for lossless float output.
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -126,6 +127,85 @@ int pt_output_basename(const char* name, int samples, char* out, int cap) {
   return (int)s.size();
 }
 
+}  // extern "C"
+
+// Radiance RGBE (.hdr) as image::saveHDR writes it through stb_image_write (src/image.cpp:41-45; the call saveImage()
+// keeps commented out, main.cpp:106), with saveImage()'s x mirror and division by the sample count.  Byte-identical to
+// the reference-compiled writer on tests/golden/ref_hdr.json.  The format: a text header, then per scanline either flat
+// RGBE quadruples (width < 8 or >= 32768) or the marker {2, 2, width hi, width lo} followed by the four byte planes
+// (R, G, B, E), each run-length coded: (128 + n, value) for n <= 127 equal bytes — only runs of at least three are
+// coded that way — and (n, n literal bytes) for n <= 128 others.
+namespace {
+void to_rgbe(const float* rgb, uint8_t out[4]) {
+  const float top = std::max(rgb[0], std::max(rgb[1], rgb[2]));
+  if (top < 1e-32) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    return;
+  }
+  int e = 0;
+  const float scale = (float)frexp(top, &e) * 256.0f / top;  // mantissa of the largest channel lands in [128, 256)
+  out[0] = (uint8_t)(rgb[0] * scale), out[1] = (uint8_t)(rgb[1] * scale), out[2] = (uint8_t)(rgb[2] * scale);
+  out[3] = (uint8_t)(e + 128);
+}
+void rle_plane(const uint8_t* v, int n, std::vector<uint8_t>& out) {
+  int at = 0;
+  while (at < n) {
+    int run = at;  // start of the next run of >= 3 equal bytes, or n when there is none
+    while (run + 2 < n && !(v[run] == v[run + 1] && v[run] == v[run + 2])) ++run;
+    const bool found = run + 2 < n;
+    if (!found) run = n;
+    for (; at < run;) {  // literals up to the run
+      const int len = std::min(run - at, 128);
+      out.push_back((uint8_t)len);
+      out.insert(out.end(), v + at, v + at + len);
+      at += len;
+    }
+    if (found) {
+      int end = run;
+      while (end < n && v[end] == v[at]) ++end;
+      for (; at < end;) {
+        const int len = std::min(end - at, 127);
+        out.push_back((uint8_t)(128 + len));
+        out.push_back(v[at]);
+        at += len;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int pt_save_hdr(const char* path, const float* rgb_sum, int w, int h, float samples) {
+  if (!path || !rgb_sum || w <= 0 || h <= 0) return -1;
+  std::vector<uint8_t> out;
+  char head[160];
+  const int hn = snprintf(head, sizeof head,
+                          "#?RADIANCE\n# Written by stb_image_write.h\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=          1.0000000000000\n\n-Y %d +X %d\n", h, w);
+  out.insert(out.end(), head, head + hn);
+  std::vector<uint8_t> planes(4 * (size_t)w);
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      const float* s = rgb_sum + 3 * ((size_t)(w - 1 - x) + (size_t)y * w);  // saveImage(): setPixel(width - 1 - x, y, pix / samples)
+      const float px[3] = {s[0] / samples, s[1] / samples, s[2] / samples};
+      uint8_t q[4];
+      to_rgbe(px, q);
+      for (int c = 0; c < 4; ++c) planes[(size_t)c * w + x] = q[c];
+    }
+    if (w < 8 || w >= 32768) {
+      for (int x = 0; x < w; ++x)
+        for (int c = 0; c < 4; ++c) out.push_back(planes[(size_t)c * w + x]);
+    } else {
+      out.push_back(2), out.push_back(2), out.push_back((uint8_t)((w >> 8) & 0xff)), out.push_back((uint8_t)(w & 0xff));
+      for (int c = 0; c < 4; ++c) rle_plane(planes.data() + (size_t)c * w, w, out);
+    }
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) return -1;
+  const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+  fclose(f);
+  return ok ? 0 : -1;
+}
+
+extern "C" {
 // Little-endian PFM, rows bottom-to-top per the format; raw orientation (no x mirror),
 // averaged radiance — the loss-free companion to the PNG for PSNR work.
 int pt_save_pfm(const char* path, const float* rgb_sum, int w, int h, float samples) {

@@ -3,7 +3,7 @@
 // state.iterations iterations, write the PNG saveImage() would write.  Flags exist only because
 // the reference takes resolution, iteration count and depth from the scene file (scene.cpp:103-114).
 //
-//   pt_render SCENE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm]
+//   pt_render SCENE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] [--hdr]
 //                       [--arith exact|fma|fast] [--gpus K] [--stamp] [--aa] [--preview N]
 //
 // Without --gpus the run goes through the pathtrace.h-compatible shim (pathtraceInit / pathtrace per
@@ -29,12 +29,12 @@
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::printf("Usage: %s SCENEFILE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] "
+    std::printf("Usage: %s SCENEFILE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] [--hdr] "
                 "[--arith exact|fma|fast] [--gpus K] [--stamp] [--aa] [--preview N]\n", argv[0]);
     return 1;
   }
   int rw = 0, rh = 0, spp = 0, depth = 0, gpus = -1, arith = PT_ARITH_EXACT, preview = 0;
-  bool pfm = false, stamp = false, aa = false;
+  bool pfm = false, hdr = false, stamp = false, aa = false;
   std::string out;
   for (int i = 2; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--res") && i + 1 < argc) std::sscanf(argv[++i], "%dx%d", &rw, &rh);
@@ -44,6 +44,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--preview") && i + 1 < argc) preview = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--pfm")) pfm = true;
+    else if (!std::strcmp(argv[i], "--hdr")) hdr = true;  // the Radiance file of image::saveHDR (main.cpp:106, commented out there)
     else if (!std::strcmp(argv[i], "--stamp")) stamp = true;
     else if (!std::strcmp(argv[i], "--aa")) aa = true;  // extension: stochastic anti-aliasing (PtOptions.aa_jitter)
     else if (!std::strcmp(argv[i], "--arith") && i + 1 < argc) {
@@ -100,6 +101,8 @@ int main(int argc, char** argv) {
       std::printf("Saved %s.png.\n", base.c_str());
     if (pfm && pt_save_pfm((base + ".pfm").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
       std::printf("Saved %s.pfm.\n", base.c_str());
+    if (hdr && pt_save_hdr((base + ".hdr").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
+      std::printf("Saved %s.hdr.\n", base.c_str());
     pathtraceFree();
   } else {
     int ndev = 0;
@@ -149,14 +152,16 @@ int main(int argc, char** argv) {
     std::printf("%dx%d, %d spp, depth %d on %d GPU(s): %.3f s, %.2f Msamples/s\n", W, H, iters, scene->state.traceDepth, gpus,
                 secs, (double)W * H * iters / secs / 1e6);
     if (pt_write_png_rgb8((base + ".png").c_str(), rgb8.data(), W, H) == 0) std::printf("Saved %s.png.\n", base.c_str());
-    if (pfm) {
+    if (pfm || hdr) {
       scene->state.image.resize((size_t)W * H * 3);
       if (pt_group_gather(grp, scene->state.image.data())) {
         std::fprintf(stderr, "HIP error (pt_group_gather): %s\n", pt_last_error());
         return EXIT_FAILURE;
       }
-      if (pt_save_pfm((base + ".pfm").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
+      if (pfm && pt_save_pfm((base + ".pfm").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
         std::printf("Saved %s.pfm.\n", base.c_str());
+      if (hdr && pt_save_hdr((base + ".hdr").c_str(), scene->state.image.data(), W, H, (float)iters) == 0)
+        std::printf("Saved %s.hdr.\n", base.c_str());
     }
     pt_group_destroy(grp);
   }

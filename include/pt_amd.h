@@ -292,6 +292,10 @@ int pt_write_png_rgb8(const char* path, const uint8_t* rgb8, int w, int h);
  * the reference's); writes at most cap bytes incl. the terminator, returns the full length. */
 int pt_output_basename(const char* name, int samples, char* out, int cap);
 int pt_save_pfm(const char* path, const float* rgb_sum, int w, int h, float samples);
+/* image::saveHDR (src/image.cpp:41-45, stbi_write_hdr; main.cpp:106 keeps the call commented out) with saveImage()'s x
+ * mirror and division by `samples`: Radiance RGBE, run-length coded, byte for byte what the reference's writer emits
+ * (tests/golden/ref_hdr.json, made by the reference's image.cpp + stb.cpp compiled in place). */
+int pt_save_hdr(const char* path, const float* rgb_sum, int w, int h, float samples);
 
 #ifdef __cplusplus
 }

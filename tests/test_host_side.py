@@ -197,3 +197,21 @@ def test_reference_scene_files_parse_like_the_synthesised_ones(oracle, name, sce
     assert all(bytes(a) == bytes(b) for a, b in zip(sc.materials(), syn.materials()))
     assert all(bytes(a) == bytes(b) for a, b in zip(sc.bvh(), oracle.bvh()))
     assert sc.iterations == syn.iterations and sc.trace_depth == syn.trace_depth and sc.image_name == syn.image_name
+
+
+def test_save_hdr_bytes_equal_the_reference_writer(tmp_path):
+    """tests/golden/ref_hdr.json: the files the REFERENCE's image::saveHDR (src/image.cpp:41-45 + stb, compiled in place by
+    oracle/ref_image_harness.cpp, filled like saveImage()) wrote for a 300-pixel-wide image (run-length path: runs longer
+    than 127, literal stretches longer than 128, tiny / huge / zero pixels) and a 5-pixel-wide one (flat RGBE).
+    pt_save_hdr writes the same bytes."""
+    g = json.load(open(os.path.join(HERE, "golden", "ref_hdr.json")))
+    assert len(g["cases"]) == 2
+    for case in g["cases"]:
+        w, h = case["width"], case["height"]
+        s = np.array(case["sum_bits"], np.uint32).view(np.float32).reshape(h * w, 3)
+        path = str(tmp_path / f"o{w}.hdr")
+        capi.save_hdr(path, s, w, h, g["samples"])
+        got = open(path, "rb").read()
+        want = bytes.fromhex(case["hdr_file_hex"])
+        assert got[:80] == want[:80]
+        assert got == want, f"{w}x{h}: first difference at byte {next(i for i, (a, b) in enumerate(zip(got, want)) if a != b) if len(got) == len(want) else (len(got), len(want))}"
