@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Fuzz the GPU renderer against the oracle on random scenes (bit-exact, PORTABLE math).
-usage: tools/fuzz_parity.py [first_seed] [count]"""
+usage: tools/fuzz_parity.py [first_seed] [count] [debug_flags]   (debug_flags 256: the uniform-grid walk forced on every
+scene, also mesh scenes every fifth seed)"""
 import os, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +11,7 @@ from oracle import binding as ob
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ob.build(); ob.set_math_mode(ob.PORTABLE)
 bad = 0
 d = tempfile.mkdtemp()
@@ -21,8 +23,13 @@ for seed in range(first, first + count):
     spp = int(rs.choice([2, 5]))
     clustered = bool(rs.randint(2))
     kw = [dict(), dict(unfused_bounces=True), dict(unfused_primary=True), dict(iters_per_batch=1), dict(num_queues=4)][rs.randint(5)]
-    path = scenes.write_scene(scenes.random_scene_text(seed, n, res=res, depth=depth, clustered=clustered), os.path.join(d, f"s{seed}.txt"))
+    text = scenes.random_scene_text(seed, n, res=res, depth=depth, clustered=clustered)
+    if flags and seed % 5 == 0:
+        text = scenes.mesh_scene_text(res=res, grid=int(rs.choice([0, 3, 5])))
+        depth = 8
+    path = scenes.write_scene(text, os.path.join(d, f"s{seed}.txt"))
     sc = capi.Scene(path, res=res)
+    kw = dict(kw, debug_flags=flags)
     r = capi.Renderer(sc, **kw); r.render(1, spp); img = r.readback(); r.free()
     ob.load_scene(path, res=res)
     ref = ob.render(1, spp, depth=depth, variant=ob.RETIRE, nthreads=min(16, os.cpu_count() or 1))
