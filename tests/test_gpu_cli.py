@@ -25,12 +25,15 @@ def test_pt_render_matches_c_abi(scene_dir, tmp_path):
     assert os.path.exists(BIN), "pt_render not built"
     out = str(tmp_path / "img")
     res, spp = (160, 120), 70  # 70 iterations: the shim flushes its queue every 64 → two pt_render calls
-    p = subprocess.run([BIN, scene_dir["cornell"], "--res", f"{res[0]}x{res[1]}", "--spp", str(spp), "--out", out, "--pfm"],
+    p = subprocess.run([BIN, scene_dir["cornell"], "--res", f"{res[0]}x{res[1]}", "--spp", str(spp), "--out", out, "--pfm", "--hdr"],
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr
     assert "Msamples/s" in p.stdout and os.path.exists(f"{out}.{spp}samp.png")
     avg, w, h = read_pfm(f"{out}.{spp}samp.pfm")
     assert (w, h) == res
+    # --hdr: the Radiance file of image::saveHDR for the same image (the writer itself is pinned on the CPU side)
+    capi.save_hdr(str(tmp_path / "expect.hdr"), np.ascontiguousarray(avg), w, h, 1.0)
+    assert open(f"{out}.{spp}samp.hdr", "rb").read() == open(tmp_path / "expect.hdr", "rb").read()
     sc = capi.Scene(scene_dir["cornell"], res=res)
     r = capi.Renderer(sc)
     try:
