@@ -1657,10 +1657,10 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
 // with what is needed only at the end (throughput colour, slot) re-read from memory.  k_bounce's pipelining (next group
 // prefetched, previous group pending, survivors deferred, double-buffered LDS) costs ~40 VGPRs and 3.5 KB of LDS per wave and
 // buys nothing when a group takes ~20 us; without it the kernel needs 75 VGPRs and 4.3 KB per wave, which leaves the LDS for
-// the hot part of the scan tree (see scan_fetch).  Compiled for 6 waves per SIMD (80 VGPRs): the BVH scan runs the same at
+// the hot part of the scan tree (see scan_fetch).  Compiled for 5 waves per SIMD (no spills; at 6 the exact grid kernel spills two registers): the BVH scan runs the same at
 // 4, 5 and 6, the grid walk 3 % faster at 5 or 6 than at 4, both 7-15 % slower at 8 (64 VGPRs, spills).
 #ifndef PT_BIG_WAVES
-#define PT_BIG_WAVES 6
+#define PT_BIG_WAVES 5
 #endif
 constexpr int kBigWaves = PT_BIG_WAVES;
 template <bool GRID>
