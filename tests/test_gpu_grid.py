@@ -1,0 +1,100 @@
+"""The uniform-grid walk on scenes chosen to stress the cell walk itself: flat layouts (one cell
+along an axis), huge extents, axis-parallel rays that run exactly along cell boundaries, a camera inside the grid, objects
+much larger and much smaller than a cell, no walls at all.  Grid forced (debug_flags 256) against the oracle bit for bit,
+and against the BVH scan (512).  The everyday scenes are in tests/test_gpu_render.py / test_mesh_extension.py."""
+import os
+
+import numpy as np
+import pytest
+
+from cosc_4397_pathtracing_raytracing_project_amd import capi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def scene_text(objects, res, eye, lookat, depth=8):
+    out = [scenes._material(i, **m) for i, m in enumerate(scenes._CORNELL_MATERIALS)]
+    out.append(scenes._camera(res, 45, 8, depth, "grid", eye, lookat, (0, 1, 0)))
+    for i, (kind, mat, t, r, s) in enumerate(objects):
+        out.append(scenes._object(i, kind, mat, t, r, s))
+    return "".join(out)
+
+
+def layouts():
+    rnd = np.random.RandomState(5)
+    flat = [("cube", 0, (0, 6, 0), (0, 0, 0), (3, ".1", 3))]  # a light above a sheet of primitives in the plane y = 0
+    for ix in range(-6, 7):
+        for iz in range(-6, 7):
+            flat.append(("sphere" if (ix + iz) & 1 else "cube", 1 + (ix * 7 + iz) % 4, (ix * 0.8, 0, iz * 0.8), (0, 0, 0), (".5", ".5", ".5")))
+    far = [("cube", 0, (0, 4000, 0), (0, 0, 0), (6000, 10, 6000))]  # extent ~1e4: coordinates where float spacing is ~1e-3
+    for k in range(120):
+        far.append(("sphere" if k & 1 else "cube", 1 + k % 4, tuple(np.round(rnd.uniform(-3000, 3000, 3), 1)), tuple(rnd.randint(0, 90, 3)),
+                    tuple(np.round(rnd.uniform(100, 600, 3), 1))))
+    # axis-aligned cubes on an exact lattice, camera looking straight down the z axis through the middle: primary and
+    # mirror-bounce rays with zero direction components, running along cell boundaries
+    lattice = [("cube", 0, (0, 9, 0), (0, 0, 0), (20, ".2", 20)), ("cube", 4, (0, 0, -8), (0, 0, 0), (16, 16, ".2"))]
+    for ix in range(-3, 4):
+        for iy in range(-3, 4):
+            for iz in range(-3, 4):
+                if (ix, iy) != (0, 0):
+                    lattice.append(("cube", 1 + (ix + iy + iz) % 3, (ix * 2, iy * 2, iz * 2), (0, 0, 0), (1, 1, 1)))
+    mixed = [("cube", 0, (0, 12, 0), (0, 0, 0), (8, ".2", 8)), ("sphere", 4, (0, 0, 0), (0, 0, 0), (14, 14, 14)),  # one primitive as large as the scene
+             ("cube", 1, (0, -9, 0), (0, 0, 0), (30, ".5", 30))]
+    for k in range(200):
+        mixed.append(("sphere" if k % 3 else "cube", 1 + k % 4, tuple(np.round(rnd.uniform(-9, 9, 3), 2)), tuple(rnd.randint(0, 180, 3)),
+                      tuple(np.round(rnd.uniform(0.02, 0.3, 3), 3))))  # and many far smaller than a cell
+    return {
+        "flat": (flat, (0, 4, 9), (0, 0, 0)),
+        "far": (far, (0, 500, 9000), (0, 0, 0)),
+        "lattice_axis_rays": (lattice, (0, 0, 30), (0, 0, 0)),
+        "inside": (lattice, (1, 1, 1), (0.3, 8, -5)),  # camera inside the grid, between the cubes
+        "mixed_sizes": (mixed, (0, 2, 25), (0, 0, 0)),
+    }
+
+
+@pytest.mark.parametrize("name", ["flat", "far", "lattice_axis_rays", "inside", "mixed_sizes"])
+def test_forced_grid_on_unusual_layouts(oracle, tmp_path, name):
+    objects, eye, lookat = layouts()[name]
+    res, spp = (128, 96), 4
+    path = scenes.write_scene(scene_text(objects, res, eye, lookat), str(tmp_path / f"{name}.txt"))
+    sc = capi.Scene(path, res=res)
+    info = sc.grid(forced=True)[0]
+    imgs = {}
+    for flags in (256, 512):
+        r = capi.Renderer(sc, debug_flags=flags)
+        try:
+            r.render(1, spp)
+            imgs[flags] = r.readback()
+            assert (r.stats().grid_cells > 0) == (flags == 256)
+        finally:
+            r.free()
+    assert np.isfinite(imgs[256]).all()
+    oracle.set_math_mode(oracle.PORTABLE)
+    oracle.load_scene(path, res=res)
+    ref = oracle.render(1, spp, depth=8, variant=oracle.RETIRE, nthreads=min(16, os.cpu_count() or 1))
+    diff = (bits(imgs[256]) != bits(ref)).any(axis=1)
+    assert not diff.any(), f"{name} (grid {list(info.res)}): {diff.sum()} pixels differ from the oracle, first {np.flatnonzero(diff)[:8]}"
+    assert np.array_equal(bits(imgs[256]), bits(imgs[512]))
+    assert (imgs[256].sum(axis=1) > 0).mean() > 0.05, "the camera sees the scene"
+
+
+@pytest.mark.parametrize("arith", ["fma", "fast"])
+def test_grid_and_scan_give_the_same_image_in_every_mode(tmp_path, arith):
+    """The structure only changes which leaves are LOOKED AT, never which pass their box test: the fma / fast images are
+    identical with either structure too (same kernels' arithmetic on the same candidates)."""
+    res, spp = (160, 90), 6
+    path = scenes.write_scene(scenes.stress_scene_text((10, 10, 8), res=res), str(tmp_path / "s.txt"))
+    sc = capi.Scene(path, res=res)
+    imgs = []
+    for flags in (256, 512):
+        r = capi.Renderer(sc, debug_flags=flags, arith=arith)
+        try:
+            r.render(1, spp)
+            imgs.append(r.readback())
+        finally:
+            r.free()
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
