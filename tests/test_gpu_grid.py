@@ -98,3 +98,28 @@ def test_grid_and_scan_give_the_same_image_in_every_mode(tmp_path, arith):
         finally:
             r.free()
     assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+
+
+def test_striped_tiles_on_the_grid_compose(scene_dir):
+    """The multi-GPU partition (row-interleaved tiles, global pixel indices in the RNG) with the grid walk in both fused
+    kernels: every rank's rows, scattered back, give the single-context image bit for bit."""
+    from cosc_4397_pathtracing_raytracing_project_amd import parallel
+    res, spp = (96, 50), 4
+    w, h = res
+    sc = capi.Scene(scene_dir["stress_big"], res=res)
+
+    def render(**kw):
+        r = capi.Renderer(sc, debug_flags=256, **kw)
+        try:
+            r.render(1, spp)
+            assert r.stats().grid_cells > 0
+            return r.readback()
+        finally:
+            r.free()
+
+    full = render()
+    for world in (2, 5):
+        out = np.zeros((h, w, 3), np.float32)
+        for rank in range(world):
+            out[rank::world] = render(**parallel.striped_tile_for_rank(w, h, rank, world)).reshape(-1, w, 3)
+        assert np.array_equal(bits(out.reshape(-1, 3)), bits(full))
