@@ -91,7 +91,7 @@ struct PtContext {
   float cull_margin = 0.f;
   unsigned long long top_xor = 0;  // SceneTables::top_xor
   int lds_table_bytes = -1;        // SceneTables::lds_table_bytes
-  // uniform grid over the leaf boxes (build_grid; SceneTables::grid_*), large evenly spread scenes only
+  // uniform grid over the leaf boxes (build_grid; SceneTables::grid_*), large scenes where it beats the BVH scan (choose_traversal)
   uint32_t* d_grid_start = nullptr;
   ptd::Node* d_grid_items = nullptr;
   int grid_res[3] = {0, 0, 0};
@@ -279,8 +279,8 @@ void pack_rows(const float m16[16], float out12[12]) {
 // fetches below the top list; a grid with about one cell per primitive is walked in ~6 cells.  Results cannot change: a
 // leaf is tested exactly when the ray passes the leaf's own box (pt_device.h), the grid only has to deliver a superset
 // of those leaves, and it does because every leaf is listed in all cells its box grown by `pad` touches — `pad` is orders
-// of magnitude above the rounding of the float cell walk.  Built only when the primitives are spread evenly enough for
-// a grid to pay (references per leaf and per cell bounded); otherwise the BVH scan stays.
+// of magnitude above the rounding of the float cell walk.  Built for large scenes whose lists stay moderate; whether
+// the renderer walks it or the BVH is measured at init (choose_traversal).
 struct GridBuild {
   int res[3];
   float gmin[3], cs[3], inv_cs[3], pad;

@@ -42,7 +42,7 @@ struct SceneTables {
   // time per wave, 6 waves per SIMD: scenes with deep subtrees, bound by the latency of the per-lane scans), 0 = k_bounce<false>.
   int32_t big_kernel;
   // Uniform grid over the leaf boxes (pt_api.cpp build_grid; grid_search in pt_kernels.hip): the depth >= 1 kernel of large
-  // scenes walks it instead of the BVH when the host finds the primitives evenly spread.  A cell lists every leaf whose box,
+  // scenes walks it instead of the BVH when that is faster (measured by the host at init).  A cell lists every leaf whose box,
   // grown by grid_pad, overlaps it: cell c's records are grid_items[grid_start[c] .. grid_start[c + 1]), each a ptd::Node
   // with the leaf's box, `skip` = the leaf's threaded node index and `geom` = geom index << 8 | primitive type << 6 | bit a
   // set when the leaf is also listed in the neighbour cell a (0..5 = -x, +x, -y, +y, -z, +z).  A leaf is a candidate exactly when the ray passes its own box

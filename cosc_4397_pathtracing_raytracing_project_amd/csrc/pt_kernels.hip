@@ -1173,7 +1173,7 @@ PT_DEV void carry_drain_to(Carry<SMALL, NPAR>& c, int mark, int lane, const ptd:
   while (c.processed - mark < 0) carry_chunk(c, min(64, c.count), lane, nodes, geoms);
 }
 
-// ── uniform grid walk (SceneTables::grid_*; large scenes with evenly spread primitives) ─────────────────────────────
+// ── uniform grid walk (SceneTables::grid_*; large scenes, when faster than the BVH scan) ───────────────────────────────
 // Second ring of a wave: cell records a ray came across, waiting for their leaf-box test.  Entry: record index << 10 |
 // direction the ray entered the cell from (0..5 = through its -x, +x, -y, +y, -z, +z face, 7 = first cell) << 7 |
 // group parity << 6 | owner lane.

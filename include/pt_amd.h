@@ -150,8 +150,8 @@ typedef struct PtStats {
   int32_t bounces_fused;              /* 1: depths >= 1 ran in the fused bounce kernel; the timed launches
                                          (intersect_ms / intersect_launches) are then those kernels      */
   int32_t arith;                      /* PT_ARITH_* in use                                               */
-  int32_t grid_cells;                 /* > 0: depths >= 1 walk the uniform grid over the leaf boxes (large, evenly spread
-                                         scenes) with this many cells; 0: the BVH scan                  */
+  int32_t grid_cells;                 /* > 0: the fused kernels walk the uniform grid over the leaf boxes (large scenes on
+                                         which it beat the BVH scan at pt_init) with this many cells; 0: the BVH         */
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,
