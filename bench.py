@@ -165,13 +165,12 @@ def main() -> None:
         torch.cuda.synchronize()
 
     r = make_renderer(not args.no_kernel_events)
-    # warm-up: untimed iterations on a scratch accumulation (restarted below)
+    # warm-up: untimed iterations, then the accumulation is restarted on the same (now touched) buffers
     if args.warmup > 0:
         r.render(1, args.warmup)
         r.readback_device(tile.data_ptr())
         parallel.gather_tiles(tile, W, H, rank, world, striped=striped)
-    r.free()
-    r = make_renderer(not args.no_kernel_events)
+        r.clear()
 
     barrier()
     t0 = time.perf_counter()
@@ -277,8 +276,7 @@ def main() -> None:
             rr = make_renderer(True, arith=m)
             rr.render(1, min(args.warmup, 50) or 1)
             rr.readback_device(tile.data_ptr())
-            rr.free()
-            rr = make_renderer(True, arith=m)
+            rr.clear()  # as for the headline run: warm-up and timed steps on the same buffers
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             rr.render(1, msteps)

@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
     L.pt_ctx_save_u8.argtypes = [C.c_void_p, C.c_float, _u8p]
     L.pt_ctx_get_stats.argtypes = [C.c_void_p, C.POINTER(PtStats)]
     L.pt_ctx_reset_stats.argtypes = [C.c_void_p]
+    L.pt_ctx_clear.argtypes = [C.c_void_p]
     L.pt_ctx_pixel_count.argtypes = [C.c_void_p]
     L.pt_group_create.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), _ip, C.c_int, C.POINTER(C.c_void_p)]
     L.pt_group_destroy.argtypes = [C.c_void_p]
@@ -299,6 +300,10 @@ class Renderer:
 
     def reset_stats(self) -> None:
         _check(lib().pt_reset_stats())
+
+    def clear(self) -> None:
+        """Restart the accumulation (SUM image and statistics zeroed) on the same, already touched buffers."""
+        _check(lib().pt_clear())
 
     def free(self) -> None:
         if self._live:

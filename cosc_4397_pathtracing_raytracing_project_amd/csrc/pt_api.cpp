@@ -997,6 +997,13 @@ int pt_ctx_reset_stats(PtContext* c) {
   return 0;
 }
 
+int pt_ctx_clear(PtContext* c) {
+  if (need(c, "pt_clear")) return -1;
+  if (pt_ctx_sync(c)) return -1;
+  HIP_OK(hipMemsetAsync(c->d_image, 0, 3 * (size_t)c->N * sizeof(float), c->stream));
+  return pt_ctx_reset_stats(c);
+}
+
 // ---- the reference's single-instance API (pathtrace.h) on a default context -------------
 int pt_free(void) {  // pathtraceFree() before init / twice is legal (main.cpp:134)
   PtContext* c = g_default;
@@ -1017,6 +1024,7 @@ int pt_preview_rgba8(int iterations, uint8_t* rgba_host) { return pt_ctx_preview
 int pt_preview_rgba8_device(int iterations, void* rgba_dev) { return pt_ctx_preview_rgba8_device(g_default, iterations, rgba_dev); }
 int pt_get_stats(PtStats* out) { return pt_ctx_get_stats(g_default, out); }
 int pt_reset_stats(void) { return pt_ctx_reset_stats(g_default); }
+int pt_clear(void) { return pt_ctx_clear(g_default); }
 
 // ---- stage entry points (tests; default context) ------------------------------------------------
 

@@ -218,6 +218,10 @@ int pt_preview_rgba8(int iterations, uint8_t* rgba_host);
 int pt_preview_rgba8_device(int iterations, void* rgba_dev); /* same, into a device buffer (the PBO) */
 int pt_get_stats(PtStats* out);
 int pt_reset_stats(void);
+/* Restart the accumulation without giving up the renderer: the SUM image and the statistics are zeroed, every buffer
+ * stays allocated (and warm).  What the reference does by pathtraceFree() + pathtraceInit() when the camera moves
+ * (main.cpp:134-135), minus the teardown. */
+int pt_clear(void);
 const char* pt_last_error(void);
 int pt_library_has_ablations(void); /* 1: -DPT_ABLATE build (debug_flags bits 0-3 honoured) */
 /* saveImage()'s per-pixel conversion (main.cpp:91-97 x mirror, image.cpp:26-30 clamp * 255 truncated) on the
@@ -239,6 +243,7 @@ int pt_ctx_preview_rgba8(PtContext* c, int iterations, uint8_t* rgba_host);
 int pt_ctx_preview_rgba8_device(PtContext* c, int iterations, void* rgba_dev);
 int pt_ctx_get_stats(PtContext* c, PtStats* out);
 int pt_ctx_reset_stats(PtContext* c);
+int pt_ctx_clear(PtContext* c);
 const float* pt_ctx_device_image(PtContext* c); /* device pointer of the tile SUM image */
 void* pt_ctx_stream(PtContext* c);              /* the context's hipStream_t */
 int pt_ctx_pixel_count(const PtContext* c);

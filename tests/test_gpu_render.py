@@ -166,6 +166,26 @@ def test_striped_tiles_compose(scene_dir):
         assert np.array_equal(bits(out.reshape(-1, 3)), bits(full))
 
 
+def test_clear_restarts_the_accumulation(scene_dir):
+    """pt_clear: SUM image and statistics back to zero on the same buffers — what follows equals a fresh renderer's
+    output bit for bit (bench.py warms up and measures on one renderer this way)."""
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    res, spp = (128, 96), 6
+    fresh, _ = gpu_render(scene_dir["cornell"], res, spp)
+    r = capi.Renderer(capi.Scene(scene_dir["cornell"], res=res), iters_per_batch=4)
+    try:
+        r.render(1, 3)
+        assert r.stats().samples == res[0] * res[1] * 3
+        r.clear()
+        assert r.stats().samples == 0 and not r.readback().any()
+        r.render(1, spp)
+        again = r.readback()
+        assert r.stats().samples == res[0] * res[1] * spp
+    finally:
+        r.free()
+    assert np.array_equal(bits(again), bits(fresh))
+
+
 def test_determinism_and_reinit(scene_dir):
     a, _ = gpu_render(scene_dir["cornell"], (128, 128), 4)
     b, _ = gpu_render(scene_dir["cornell"], (128, 128), 4, num_queues=64)
