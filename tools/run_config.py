@@ -20,8 +20,7 @@ def run(scene="stress", res=(1920, 1080), spp=100, depth=8, grid=(22, 22, 21), a
     sc = capi.Scene(path, res=(w, h))
     kw = dict(iters_per_batch=iters_per_batch, time_kernels=True, debug_flags=debug_flags, arith=arith)
     r = capi.Renderer(sc, **kw)
-    r.render(1, max(2, spp // 10)); r.sync(); r.free()
-    r = capi.Renderer(sc, **kw)
+    r.render(1, max(2, spp // 10)); r.clear()  # warm-up, then the accumulation restarts on the same buffers
     t0 = time.perf_counter(); r.render(1, spp); img = r.readback(); dt = time.perf_counter() - t0
     st = r.stats(); r.free()
     live = np.array(st.live_rays[:depth], float)
