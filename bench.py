@@ -274,7 +274,7 @@ def main() -> None:
             if m in modes:
                 continue
             rr = make_renderer(True, arith=m)
-            rr.render(1, min(args.warmup, 50) or 1)
+            rr.render(1, 200)  # untimed; long enough for the memory the previous leg's renderer released to settle
             rr.readback_device(tile.data_ptr())
             rr.clear()  # as for the headline run: warm-up and timed steps on the same buffers
             torch.cuda.synchronize()
