@@ -87,6 +87,37 @@ def test_intersect_stress_scene_secondary_rays(gpu, oracle):
     assert_hits_equal(R.stage_intersect(o, d), oracle.intersect(o, d))
 
 
+@pytest.mark.parametrize("s,name", [(0, "cornell"), (1, "ref_twisted")])
+@pytest.mark.parametrize("arith", ["exact"])
+def test_intersect_against_reference_compiled_goldens(scene_dir, s, name, arith):
+    """DIRECT pin of the device code to the reference's own code, no oracle in between: the rays of
+    tests/golden/ref_isect.bin.gz go through pt_stage_intersect and must give, bit for bit, the t / point / normal
+    that the reference's boxIntersectionTest / sphereIntersectionTest (intersections.h:48-144, compiled in place by
+    oracle/ref_hot_harness.cpp) returned for the winning primitive.  Which primitive wins is assembled from the golden's
+    per-primitive results by golden_io.expected_closest_hits (leaf-box filter + smallest t, first visited on ties)."""
+    import os
+    import golden_io as gio
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    gold = gio.load("ref_isect.bin.gz")
+    path = scene_dir[name] if name in scene_dir else os.path.join(gio.GOLDEN, "scenes", name + ".txt")
+    sc = capi.Scene(path)
+    rows, geom = gio.expected_closest_hits(gold, s, sc.bvh())
+    rays = gio.f32(gold[f"rays_{s}"])
+    r = capi.Renderer(sc, arith=arith)
+    try:
+        got = r.stage_intersect(np.ascontiguousarray(rays[:, 0:3].T), np.ascontiguousarray(rays[:, 3:6].T))
+    finally:
+        r.free()
+    hit = geom >= 0
+    assert hit.sum() > 800
+    assert np.array_equal(got["t"] > 0, hit), np.flatnonzero((got["t"] > 0) != hit)[:8]
+    assert np.array_equal(bits(got["t"][hit]), rows[hit, 0])
+    assert gio.same_bits_or_both_nan(bits(got["pt"].T[hit]), rows[hit, 1:4]).all()
+    assert gio.same_bits_or_both_nan(bits(got["nrm"].T[hit]), rows[hit, 4:7]).all()
+    mats = np.array([g.materialid for g in sc.geoms()], np.int32)
+    assert np.array_equal(got["mat"][hit], mats[geom[hit]])
+
+
 @pytest.mark.parametrize("scene,res,depth_total", [("cornell", (320, 200), 8), ("stress", (160, 90), 8), ("sphere", (128, 128), 4)])
 def test_shade_all_depths(gpu, oracle, scene, res, depth_total):
     """Walk real paths through all depths: at each depth the GPU shade of the live set must equal the
