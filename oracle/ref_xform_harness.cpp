@@ -1,9 +1,9 @@
 // oracle/ref_xform_harness.cpp — TEST INFRASTRUCTURE ONLY (golden generation).
 //
-// Of the reference's scene path, what compiles in this image without stand-in headers is
-// src/utilities.cpp (+ the vendored header-only GLM 0.9.6.3): scene.cpp / intersections.h /
-// pathtrace.cu all reach <cuda_runtime.h> or <cuda.h>, which do not exist here.  (The image
-// writer, src/image.cpp + src/stb.cpp, compiles too: see ref_image_harness.cpp.)  This harness links the reference's own
+// The first of the reference-compiled harnesses (round 1): src/utilities.cpp + the vendored header-only GLM 0.9.6.3
+// need no CUDA header at all.  (scene.cpp / intersections.h reach <cuda_runtime.h>; a genuine one ships inside this
+// image's triton package and ref_hot_harness.cpp compiles them against it.  The image writer, src/image.cpp +
+// src/stb.cpp: ref_image_harness.cpp.)  This harness links the reference's own
 // utilityCore::buildTransformationMatrix (src/utilities.cpp:64-72) and calls GLM's
 // inverse / inverseTranspose exactly as scene.cpp:83-86 does, plus the handful of
 // GLM vector primitives the hot path uses, and prints the results as JSON.  The
