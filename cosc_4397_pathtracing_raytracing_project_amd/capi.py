@@ -127,6 +127,8 @@ def lib() -> C.CDLL:
     L.pt_ctx_clear.argtypes = [C.c_void_p]
     L.pt_ctx_pixel_count.argtypes = [C.c_void_p]
     L.pt_group_create.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), _ip, C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_group_create_ex.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.pt_group_transport.argtypes = [C.c_void_p]
     L.pt_group_destroy.argtypes = [C.c_void_p]
     L.pt_group_size.argtypes = [C.c_void_p]
     L.pt_group_context.argtypes = [C.c_void_p, C.c_int]
@@ -352,15 +354,25 @@ def pt_free() -> None:
     _check(lib().pt_free())
 
 
-class Group:
-    """pt_group_*: one process driving several GPUs, row-interleaved tiles, one RCCL gather at write-out."""
+TRANSPORT = {"auto": 0, "rccl": 1, "copy": 2}  # PT_GROUP_TRANSPORT_* (include/pt_amd.h)
 
-    def __init__(self, scene: Scene, devices: Sequence[int], **kw):
+
+class Group:
+    """pt_group_*: one process driving several GPUs, row-interleaved tiles, one exchange at write-out (RCCL; peer /
+    device copies when `devices` names a device more than once — several contexts on one GPU — or on request)."""
+
+    def __init__(self, scene: Scene, devices: Sequence[int], transport: str = "auto", **kw):
         self.scene = scene
         self._h = C.c_void_p()
         dev = np.asarray(list(devices), np.int32)
         opt = make_options(**kw)
-        _check(lib().pt_group_create(C.byref(scene.desc), C.byref(opt), _i(dev), len(dev), C.byref(self._h)))
+        _check(lib().pt_group_create_ex(C.byref(scene.desc), C.byref(opt), _i(dev), len(dev), TRANSPORT[transport],
+                                        C.byref(self._h)))
+
+    @property
+    def transport(self) -> str:
+        t = lib().pt_group_transport(self._h)
+        return {v: k for k, v in TRANSPORT.items()}[t]
 
     def render(self, iter_first: int, iter_count: int) -> None:
         _check(lib().pt_group_render(self._h, int(iter_first), int(iter_count)))

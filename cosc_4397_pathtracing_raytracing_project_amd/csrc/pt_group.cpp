@@ -10,10 +10,20 @@
 // tiles into devices[0] on a ncclCommInitAll communicator — xGMI is point-to-point, the tiles go straight to the
 // root over their own links, there is no ring and no reduction.  Placement of the interleaved rows (a strided 2-D
 // copy on the root device) and one D2H copy follow.
+//
+// Two transports for that one exchange (PtGroup::transport, pt_group_create_ex):
+//   RCCL  the grouped ncclSend / ncclRecv above — the default for distinct devices;
+//   COPY  hipMemcpyPeerAsync (hipMemcpyAsync when source and root are the same device) of every tile into the same
+//         receive buffer at the same offsets, ordered after the tile's producer by an event the root's stream waits
+//         on.  RCCL cannot put two ranks of one communicator on one device, so this is what a group whose device
+//         list names a device more than once (e.g. {0, 0, 0}: several contexts, one GPU) uses automatically; it
+//         makes the whole multi-context path — per-context streams, receive offsets, strided row placement,
+//         preview exchange — testable on a one-GPU box, and is a fallback where RCCL is unwanted.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/pt_amd.h"
@@ -32,6 +42,8 @@
 
 struct PtGroup {
   int W = 0, H = 0, n = 0;
+  int transport = PT_GROUP_TRANSPORT_RCCL;  // resolved (never AUTO) after pt_group_create_ex
+  std::vector<hipEvent_t> ready;            // COPY transport: "tile i is complete" (recorded on context i's stream)
   std::vector<int> devices;
   std::vector<PtContext*> ctx;
   std::vector<ncclComm_t> comms;
@@ -43,6 +55,8 @@ struct PtGroup {
   uint8_t* d_recv8 = nullptr; // same for the converted bytes (3 B/pixel)
   uint8_t* d_full8 = nullptr;
   std::vector<uint8_t*> d_prev;  // per device: RGBA8 preview of its tile (sendImageToPBO)
+  uint8_t* d_recv_prev = nullptr;  // root: preview tiles of devices 1..n-1 / assembled preview (kept: previews recur)
+  uint8_t* d_full_prev = nullptr;
 };
 
 namespace {
@@ -54,8 +68,14 @@ void release(PtGroup* g) {
       (void)hipSetDevice(g->devices[i]);
       (void)ncclCommDestroy(g->comms[i]);
     }
+  for (size_t i = 0; i < g->ready.size(); ++i)
+    if (g->ready[i]) {
+      (void)hipSetDevice(g->devices[i]);
+      (void)hipEventDestroy(g->ready[i]);
+    }
   if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
-  for (void* p : {(void*)g->d_recv, (void*)g->d_full, (void*)g->d_recv8, (void*)g->d_full8})
+  for (void* p : {(void*)g->d_recv, (void*)g->d_full, (void*)g->d_recv8, (void*)g->d_full8, (void*)g->d_recv_prev,
+                  (void*)g->d_full_prev})
     if (p) (void)hipFree(p);
   for (size_t i = 0; i < g->d_prev.size(); ++i)
     if (g->d_prev[i]) {
@@ -66,11 +86,33 @@ void release(PtGroup* g) {
   delete g;
 }
 
-// One grouped send/recv: device i >= 1 sends `elems_per_pixel * pixels_i` elements of `src(i)` on its own stream,
-// the root receives them back to back on its stream.
+// COPY transport: the root's stream waits for tile i's producer, then pulls the tile into the receive buffer.
+int exchange_copy(PtGroup* g, size_t bytes_per_pixel, char* root_recv, const void* const* src) {
+  hipStream_t root = (hipStream_t)pt_ctx_stream(g->ctx[0]);
+  for (int i = 1; i < g->n; ++i) {
+    const size_t bytes = bytes_per_pixel * (size_t)pt_ctx_pixel_count(g->ctx[i]);
+    HIP_OK(hipSetDevice(g->devices[i]));
+    HIP_OK(hipEventRecord(g->ready[i], (hipStream_t)pt_ctx_stream(g->ctx[i])));
+    HIP_OK(hipSetDevice(g->devices[0]));
+    HIP_OK(hipStreamWaitEvent(root, g->ready[i], 0));
+    char* dst = root_recv + bytes_per_pixel * g->recv_off[i];
+    if (g->devices[i] == g->devices[0]) HIP_OK(hipMemcpyAsync(dst, src[i], bytes, hipMemcpyDeviceToDevice, root));
+    else HIP_OK(hipMemcpyPeerAsync(dst, g->devices[0], src[i], g->devices[i], bytes, root));
+  }
+  return 0;
+}
+
+// The one exchange of a write-out: device i >= 1 hands `elems_per_pixel * pixels_i` elements of `src(i)` to the root,
+// which receives them back to back (recv_off) on its stream.  RCCL: one grouped send/recv, each send on its own
+// device's stream.
 template <typename T, typename SrcFn>
 int exchange(PtGroup* g, ncclDataType_t type, int elems_per_pixel, T* root_recv, SrcFn src) {
   if (g->n == 1) return 0;
+  if (g->transport == PT_GROUP_TRANSPORT_COPY) {
+    std::vector<const void*> srcs(g->n, nullptr);
+    for (int i = 1; i < g->n; ++i) srcs[i] = src(i);
+    return exchange_copy(g, sizeof(T) * (size_t)elems_per_pixel, reinterpret_cast<char*>(root_recv), srcs.data());
+  }
   NCCL_OK(ncclGroupStart());
   int rc = 0;
   for (int i = 1; i < g->n && !rc; ++i) {  // an error inside the group must still close it
@@ -89,6 +131,14 @@ int exchange(PtGroup* g, ncclDataType_t type, int elems_per_pixel, T* root_recv,
   return rc;
 }
 
+// After a failed exchange / placement some sends, receives or copies may already be queued on the devices' streams:
+// drain them (ignoring further errors, keeping the first message) before the caller sees the failure.
+int fail_after_drain(PtGroup* g) {
+  const std::string first = pt_last_error();
+  for (PtContext* c : g->ctx) (void)pt_ctx_sync(c);
+  return pt_fail("%s", first.c_str());
+}
+
 // Rows of device i (tile order) -> rows i, i+n, ... of the frame, on the root's stream.
 template <typename T>
 int place_rows(PtGroup* g, int i, const T* tile, T* full, size_t bytes_per_pixel) {
@@ -102,17 +152,24 @@ int place_rows(PtGroup* g, int i, const T* tile, T* full, size_t bytes_per_pixel
 
 extern "C" {
 
-int pt_group_create(const PtSceneDesc* scene, const PtOptions* base, const int* devices, int num_devices, PtGroup** out) {
+int pt_group_create_ex(const PtSceneDesc* scene, const PtOptions* base, const int* devices, int num_devices, int transport,
+                       PtGroup** out) {
   if (!out) return pt_fail("pt_group_create: null output");
   *out = nullptr;
   if (!scene || !devices || num_devices <= 0) return pt_fail("pt_group_create: bad argument");
+  if (transport != PT_GROUP_TRANSPORT_AUTO && transport != PT_GROUP_TRANSPORT_RCCL && transport != PT_GROUP_TRANSPORT_COPY)
+    return pt_fail("pt_group_create: unknown transport %d", transport);
   const int W = scene->camera.resolution[0], H = scene->camera.resolution[1];
   if (num_devices > H) return pt_fail("pt_group_create: more devices (%d) than image rows (%d)", num_devices, H);
+  bool shared = false;  // a device named more than once: several contexts on one GPU
   for (int i = 0; i < num_devices; ++i)
-    for (int j = 0; j < i; ++j)
-      if (devices[i] == devices[j]) return pt_fail("pt_group_create: device %d listed twice", devices[i]);
+    for (int j = 0; j < i; ++j) shared |= devices[i] == devices[j];
+  if (shared && transport == PT_GROUP_TRANSPORT_RCCL)
+    return pt_fail("pt_group_create: a device is listed twice; RCCL cannot place two ranks of one communicator on one "
+                   "device (use PT_GROUP_TRANSPORT_AUTO or _COPY)");
   PtGroup* g = new PtGroup();
   g->W = W, g->H = H, g->n = num_devices;
+  g->transport = transport == PT_GROUP_TRANSPORT_AUTO ? (shared ? PT_GROUP_TRANSPORT_COPY : PT_GROUP_TRANSPORT_RCCL) : transport;
   g->devices.assign(devices, devices + num_devices);
   g->rows.resize(num_devices);
   g->recv_off.assign(num_devices, 0);
@@ -136,15 +193,30 @@ int pt_group_create(const PtSceneDesc* scene, const PtOptions* base, const int* 
     }
     g->ctx.push_back(c);
   }
-  g->comms.assign(num_devices, nullptr);
-  ncclResult_t r = ncclCommInitAll(g->comms.data(), num_devices, g->devices.data());
-  if (r != ncclSuccess) {
-    release(g);
-    return pt_fail("ncclCommInitAll(%d devices) failed: %s", num_devices, ncclGetErrorString(r));
+  if (g->transport == PT_GROUP_TRANSPORT_COPY) {
+    g->ready.assign(num_devices, nullptr);
+    for (int i = 1; i < num_devices; ++i)
+      if (hipSetDevice(devices[i]) != hipSuccess || hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming) != hipSuccess) {
+        release(g);
+        return pt_fail("pt_group_create: cannot create the tile-ready event on device %d", devices[i]);
+      }
+  } else {
+    g->comms.assign(num_devices, nullptr);
+    ncclResult_t r = ncclCommInitAll(g->comms.data(), num_devices, g->devices.data());
+    if (r != ncclSuccess) {
+      release(g);
+      return pt_fail("ncclCommInitAll(%d devices) failed: %s", num_devices, ncclGetErrorString(r));
+    }
   }
   *out = g;
   return 0;
 }
+
+int pt_group_create(const PtSceneDesc* scene, const PtOptions* base, const int* devices, int num_devices, PtGroup** out) {
+  return pt_group_create_ex(scene, base, devices, num_devices, PT_GROUP_TRANSPORT_AUTO, out);
+}
+
+int pt_group_transport(const PtGroup* g) { return g ? g->transport : -1; }
 
 int pt_group_destroy(PtGroup* g) {
   release(g);
@@ -174,10 +246,11 @@ int pt_group_gather(PtGroup* g, float* rgb_sum_host) {
   if (g->n == 1) return pt_ctx_readback(g->ctx[0], rgb_sum_host);
   if (!g->d_full) HIP_OK(hipMalloc((void**)&g->d_full, frame * 12));
   if (!g->d_recv) HIP_OK(hipMalloc((void**)&g->d_recv, g->recv_pixels * 12));
-  if (exchange(g, ncclFloat, 3, g->d_recv, [&](int i) { return pt_ctx_device_image(g->ctx[i]); })) return -1;
+  if (exchange(g, ncclFloat, 3, g->d_recv, [&](int i) { return pt_ctx_device_image(g->ctx[i]); })) return fail_after_drain(g);
   HIP_OK(hipSetDevice(g->devices[0]));
   for (int i = 0; i < g->n; ++i)
-    if (place_rows(g, i, i == 0 ? pt_ctx_device_image(g->ctx[0]) : g->d_recv + 3 * g->recv_off[i], g->d_full, 12)) return -1;
+    if (place_rows(g, i, i == 0 ? pt_ctx_device_image(g->ctx[0]) : g->d_recv + 3 * g->recv_off[i], g->d_full, 12))
+      return fail_after_drain(g);
   HIP_OK(hipMemcpyAsync(rgb_sum_host, g->d_full, frame * 12, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])));
   return pt_group_sync(g);
 }
@@ -195,10 +268,10 @@ int pt_group_gather_u8(PtGroup* g, float samples, uint8_t* rgb8_host) {
   }
   if (!g->d_full8) HIP_OK(hipMalloc((void**)&g->d_full8, frame * 3));
   if (!g->d_recv8) HIP_OK(hipMalloc((void**)&g->d_recv8, g->recv_pixels * 3));
-  if (exchange(g, ncclUint8, 3, g->d_recv8, [&](int i) { return tiles[i]; })) return -1;
+  if (exchange(g, ncclUint8, 3, g->d_recv8, [&](int i) { return tiles[i]; })) return fail_after_drain(g);
   HIP_OK(hipSetDevice(g->devices[0]));
   for (int i = 0; i < g->n; ++i)
-    if (place_rows(g, i, i == 0 ? tiles[0] : g->d_recv8 + 3 * g->recv_off[i], g->d_full8, 3)) return -1;
+    if (place_rows(g, i, i == 0 ? tiles[0] : g->d_recv8 + 3 * g->recv_off[i], g->d_full8, 3)) return fail_after_drain(g);
   HIP_OK(hipMemcpyAsync(rgb8_host, g->d_full8, frame * 3, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])));
   return pt_group_sync(g);
 }
@@ -221,21 +294,15 @@ int pt_group_preview_rgba8(PtGroup* g, int iterations, uint8_t* rgba_host) {
     HIP_OK(hipMemcpyAsync(rgba_host, g->d_prev[0], frame * 4, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])));
     return pt_group_sync(g);
   }
-  uint8_t *full = nullptr, *recv = nullptr;  // previews are occasional: scratch buffers, freed below
-  HIP_OK(hipMalloc((void**)&full, frame * 4));
-  HIP_OK(hipMalloc((void**)&recv, g->recv_pixels * 4));
-  int rc = exchange(g, ncclUint8, 4, recv, [&](int i) { return (const uint8_t*)g->d_prev[i]; });
-  if (!rc) {
-    (void)hipSetDevice(g->devices[0]);
-    for (int i = 0; i < g->n && !rc; ++i) rc = place_rows(g, i, i == 0 ? (const uint8_t*)g->d_prev[0] : recv + 4 * g->recv_off[i], full, 4);
-  }
-  if (!rc && hipMemcpyAsync(rgba_host, full, frame * 4, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])) != hipSuccess)
-    rc = pt_fail("pt_group_preview_rgba8: copy failed");
-  if (!rc) rc = pt_group_sync(g);
-  (void)hipSetDevice(g->devices[0]);
-  (void)hipFree(full);
-  (void)hipFree(recv);
-  return rc;
+  if (!g->d_full_prev) HIP_OK(hipMalloc((void**)&g->d_full_prev, frame * 4));  // kept in the group: previews recur every
+  if (!g->d_recv_prev) HIP_OK(hipMalloc((void**)&g->d_recv_prev, g->recv_pixels * 4));  // few batches; freed by release()
+  if (exchange(g, ncclUint8, 4, g->d_recv_prev, [&](int i) { return (const uint8_t*)g->d_prev[i]; })) return fail_after_drain(g);
+  HIP_OK(hipSetDevice(g->devices[0]));
+  for (int i = 0; i < g->n; ++i)
+    if (place_rows(g, i, i == 0 ? (const uint8_t*)g->d_prev[0] : g->d_recv_prev + 4 * g->recv_off[i], g->d_full_prev, 4))
+      return fail_after_drain(g);
+  HIP_OK(hipMemcpyAsync(rgba_host, g->d_full_prev, frame * 4, hipMemcpyDeviceToHost, (hipStream_t)pt_ctx_stream(g->ctx[0])));
+  return pt_group_sync(g);
 }
 
 }  // extern "C"

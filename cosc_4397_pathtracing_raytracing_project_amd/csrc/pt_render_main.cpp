@@ -4,12 +4,15 @@
 // the reference takes resolution, iteration count and depth from the scene file (scene.cpp:103-114).
 //
 //   pt_render SCENE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] [--hdr]
-//                       [--arith exact|fma|fast] [--gpus K] [--stamp] [--aa] [--preview N]
+//                       [--arith exact|fma|fast] [--gpus K | --devices LIST] [--transport rccl|copy] [--stamp] [--aa]
+//                       [--preview N]
 //
 // Without --gpus the run goes through the pathtrace.h-compatible shim (pathtraceInit / pathtrace per
 // iteration / pathtraceFree), i.e. the code path a reference main.cpp would take.  With --gpus K (K >= 1;
 // K = 0: all visible devices) it goes through pt_group_*: K devices in this one process, row-interleaved
 // tiles, one grouped RCCL send/recv at write-out (BASELINE config 4), PNG bytes converted on the devices.
+// --devices 0,0,0 names the devices explicitly; a device may appear more than once (several contexts on one GPU — the
+// exchange then uses peer / device copies instead of RCCL, PT_GROUP_TRANSPORT_COPY; --transport forces either).
 // --preview N (with --gpus): every N iterations the running average is converted on the devices and gathered
 // (pt_group_preview_rgba8 — the reference shows it after every iteration, pathtrace.cu:618) into PREFIX.preview.png.
 // Output name: PREFIX.<spp>samp.png, or with --stamp the reference's own
@@ -30,10 +33,11 @@
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::printf("Usage: %s SCENEFILE.txt [--res WxH] [--spp N] [--depth D] [--out PREFIX] [--pfm] [--hdr] "
-                "[--arith exact|fma|fast] [--gpus K] [--stamp] [--aa] [--preview N]\n", argv[0]);
+                "[--arith exact|fma|fast] [--gpus K | --devices LIST] [--transport rccl|copy] [--stamp] [--aa] [--preview N]\n", argv[0]);
     return 1;
   }
-  int rw = 0, rh = 0, spp = 0, depth = 0, gpus = -1, arith = PT_ARITH_EXACT, preview = 0;
+  int rw = 0, rh = 0, spp = 0, depth = 0, gpus = -1, arith = PT_ARITH_EXACT, preview = 0, transport = PT_GROUP_TRANSPORT_AUTO;
+  std::vector<int> device_list;
   bool pfm = false, hdr = false, stamp = false, aa = false;
   std::string out;
   for (int i = 2; i < argc; ++i) {
@@ -43,6 +47,26 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
     else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = std::atoi(argv[++i]);
     else if (!std::strcmp(argv[i], "--preview") && i + 1 < argc) preview = std::atoi(argv[++i]);
+    else if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {
+      for (const char* q = argv[++i]; *q;) {
+        char* end = nullptr;
+        device_list.push_back((int)std::strtol(q, &end, 10));
+        if (end == q) {
+          std::fprintf(stderr, "--devices wants a comma-separated list of device ordinals\n");
+          return 1;
+        }
+        q = *end == ',' ? end + 1 : end;
+      }
+      gpus = (int)device_list.size();
+    } else if (!std::strcmp(argv[i], "--transport") && i + 1 < argc) {
+      const char* a = argv[++i];
+      if (!std::strcmp(a, "rccl")) transport = PT_GROUP_TRANSPORT_RCCL;
+      else if (!std::strcmp(a, "copy")) transport = PT_GROUP_TRANSPORT_COPY;
+      else {
+        std::fprintf(stderr, "unknown transport %s\n", a);
+        return 1;
+      }
+    }
     else if (!std::strcmp(argv[i], "--pfm")) pfm = true;
     else if (!std::strcmp(argv[i], "--hdr")) hdr = true;  // the Radiance file of image::saveHDR (main.cpp:106, commented out there)
     else if (!std::strcmp(argv[i], "--stamp")) stamp = true;
@@ -111,18 +135,23 @@ int main(int argc, char** argv) {
       return 1;
     }
     if (gpus == 0) gpus = ndev;
-    if (gpus > ndev) {
+    if (device_list.empty() && gpus > ndev) {
       std::fprintf(stderr, "--gpus %d but only %d device(s) visible\n", gpus, ndev);
       return 1;
     }
     std::vector<int> devices(gpus);
-    for (int i = 0; i < gpus; ++i) devices[i] = i;
+    for (int i = 0; i < gpus; ++i) devices[i] = device_list.empty() ? i : device_list[i];
+    for (int d : devices)
+      if (d < 0 || d >= ndev) {
+        std::fprintf(stderr, "device %d named but only %d device(s) visible\n", d, ndev);
+        return 1;
+      }
     PtOptions opt{};
     opt.arith = arith;
     opt.aa_jitter = aa ? 1 : 0;
     const PtSceneDesc desc = scene->desc();
     PtGroup* grp = nullptr;
-    if (pt_group_create(&desc, &opt, devices.data(), gpus, &grp)) {
+    if (pt_group_create_ex(&desc, &opt, devices.data(), gpus, transport, &grp)) {
       std::fprintf(stderr, "HIP error (pt_group_create): %s\n", pt_last_error());
       return EXIT_FAILURE;
     }

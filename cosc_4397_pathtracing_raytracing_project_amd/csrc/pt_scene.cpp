@@ -217,7 +217,8 @@ void parseMaterial(std::istream& in, const std::string& idWord, std::vector<PtMa
 // Mesh EXTENSION (the format names "mesh", INSTRUCTION.md:246, the reference implements neither loader
 // nor kernel for it): an OBJECT of type `mesh` may carry `TRI x0 y0 z0 x1 y1 z1 x2 y2 z2` lines (object space) among its
 // TRANS / ROTAT / SCALE lines — lines the reference's loader skips (scene.cpp:66-80) — and expands into one PT_GEOM_TRIANGLE
-// primitive per line, vertices transformed to world space with the object's matrix.  OBJECT ids are checked against the
+// primitive per line, vertices transformed to world space with the object's matrix (no TRI line: one ordinary geom, see
+// below).  OBJECT ids are checked against the
 // number of objects accepted so far (`objects`), which equals geoms.size() (the reference's check, scene.cpp:37) as long as
 // no mesh has expanded.
 void parseObject(std::istream& in, const std::string& idWord, std::vector<PtGeom>& geoms, int& objects) {
@@ -250,7 +251,11 @@ void parseObject(std::istream& in, const std::string& idWord, std::vector<PtGeom
       for (size_t k = 1; k <= 9; ++k) tri.push_back(numAt(w, k));
   }
   buildTransform(trs, g.transform, g.inverseTransform, g.invTranspose);
-  if (mesh) {
+  // The extension acts only on its own syntax: a `mesh` block WITHOUT TRI lines — all a reference-format file can
+  // contain — loads as the reference's loader leaves it: ONE geom whose type keeps its initial value (scene.cpp:47-55
+  // assigns none for an unknown type line; uninitialised there, PT_GEOM_SPHERE here), so the geom index space of such
+  // a file does not shift.
+  if (mesh && !tri.empty()) {
     for (size_t k = 0; k + 8 < tri.size(); k += 9) {
       PtGeom t{};
       t.type = PT_GEOM_TRIANGLE;

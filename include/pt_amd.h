@@ -256,6 +256,18 @@ int pt_ctx_device(const PtContext* c);
  * communicator) into device devices[0], placed row by row there, one D2H copy.  Replaces the reference's single
  * device (src/preview.cpp:112 cudaGLSetGLDevice(0)) and its write-out point (src/main.cpp:86-107). */
 typedef struct PtGroup PtGroup;
+/* Transport of that one exchange.  RCCL: grouped ncclSend / ncclRecv (default for distinct devices).  COPY:
+ * hipMemcpyPeerAsync / hipMemcpyAsync of every tile into the same receive buffer, ordered by events — chosen
+ * automatically when the device list names a device more than once (several contexts on one GPU, e.g. {0, 0, 0}:
+ * RCCL cannot put two ranks of a communicator on one device), which makes the whole multi-context path runnable on a
+ * one-GPU machine; selectable explicitly as a fallback.  The assembled image is the same bit for bit. */
+#define PT_GROUP_TRANSPORT_AUTO 0
+#define PT_GROUP_TRANSPORT_RCCL 1
+#define PT_GROUP_TRANSPORT_COPY 2
+int pt_group_create_ex(const PtSceneDesc* scene, const PtOptions* base, const int* devices, int num_devices, int transport,
+                       PtGroup** out);
+int pt_group_transport(const PtGroup* g); /* the resolved transport (PT_GROUP_TRANSPORT_RCCL or _COPY) */
+/* = pt_group_create_ex(..., PT_GROUP_TRANSPORT_AUTO, out) */
 int pt_group_create(const PtSceneDesc* scene, const PtOptions* base, const int* devices, int num_devices, PtGroup** out);
 int pt_group_destroy(PtGroup* g);
 int pt_group_size(const PtGroup* g);

@@ -47,7 +47,15 @@ def layouts():
     for k in range(200):
         mixed.append(("sphere" if k % 3 else "cube", 1 + k % 4, tuple(np.round(rnd.uniform(-9, 9, 3), 2)), tuple(rnd.randint(0, 180, 3)),
                       tuple(np.round(rnd.uniform(0.02, 0.3, 3), 3))))  # and many far smaller than a cell
+    # a small scene (extent ~ 12) ten thousand units from the origin, camera beside it: |coordinate| / extent ~ 1e3, where
+    # 1e-4 * extent would be one ulp of a coordinate (the pad has to follow the coordinate magnitude)
+    off = np.array([10000.0, 9000.0, -10000.0])
+    offset = [("cube", 0, tuple(off + (0, 6, 0)), (0, 0, 0), (4, ".25", 4)), ("cube", 1, tuple(off + (0, -6, 0)), (0, 0, 0), (12, ".25", 12))]
+    for k in range(150):
+        offset.append(("sphere" if k & 1 else "cube", 1 + k % 4, tuple(np.round(off + rnd.uniform(-5, 5, 3), 2)), tuple(rnd.randint(0, 90, 3)),
+                       tuple(np.round(rnd.uniform(0.2, 0.9, 3), 2))))
     return {
+        "offset": (offset, tuple(off + (0.5, 1, 16)), tuple(off)),
         "flat": (flat, (0, 4, 9), (0, 0, 0)),
         "far": (far, (0, 500, 9000), (0, 0, 0)),
         "lattice_axis_rays": (lattice, (0, 0, 30), (0, 0, 0)),
@@ -56,7 +64,7 @@ def layouts():
     }
 
 
-@pytest.mark.parametrize("name", ["flat", "far", "lattice_axis_rays", "inside", "mixed_sizes"])
+@pytest.mark.parametrize("name", ["flat", "far", "lattice_axis_rays", "inside", "mixed_sizes", "offset"])
 def test_forced_grid_on_unusual_layouts(oracle, tmp_path, name):
     objects, eye, lookat = layouts()[name]
     res, spp = (128, 96), 4

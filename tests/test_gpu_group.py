@@ -74,6 +74,80 @@ def test_group_of_visible_devices_equals_single_context(scene_dir, arith):
         assert np.array_equal(u8, expected_u8(ref, res[0], res[1], spp))
 
 
+@pytest.mark.parametrize("k", [2, 3])
+@pytest.mark.parametrize("scene,res,spp,kw", [
+    ("cornell", (160, 101), 9, dict(arith="exact")),            # odd row count: contexts own 51/50 resp. 34/34/33 rows
+    ("cornell", (96, 64), 7, dict(arith="fast")),
+    ("stress_big", (160, 90), 4, dict(arith="exact", debug_flags=256)),  # the uniform-grid kernels (forced)
+    ("stress_big", (160, 91), 4, dict(arith="exact", debug_flags=512)),  # the BVH-scan kernels for big scenes
+])
+def test_group_of_contexts_on_one_device(scene_dir, k, scene, res, spp, kw):
+    """K contexts on device 0 (device list {0, 0, ...}): everything the multi-GPU write-out does except RCCL itself runs —
+    per-context streams, striped tiles with global pixel indices, the exchange into the root's receive buffer at
+    recv_off, the strided row placement, the float / u8 / preview variants — and must give the single-context image
+    bit for bit.  (RCCL cannot place two ranks on one device, so the exchange is PT_GROUP_TRANSPORT_COPY here.)"""
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    ref, ref8 = single(scene_dir[scene], res, spp, **kw)
+    sc1 = capi.Scene(scene_dir[scene], res=res)
+    r = capi.Renderer(sc1, **kw)
+    try:
+        r.render(1, spp)
+        want_prev = r.preview(spp)
+    finally:
+        r.free()
+    g = capi.Group(capi.Scene(scene_dir[scene], res=res), [0] * k, iters_per_batch=3, **kw)
+    try:
+        assert g.transport == "copy"
+        g.render(1, spp - 2)
+        g.render(spp - 1, 2)
+        img = g.gather()
+        u8 = g.gather_u8(spp)
+        prev = g.preview(spp)
+        img2 = g.gather()  # a second write-out reuses the group's buffers
+        rows = [(res[1] - i + k - 1) // k for i in range(k)]
+        for i in range(k):
+            assert g.stats(i).samples == rows[i] * res[0] * spp
+    finally:
+        g.free()
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(img2.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(u8, ref8) and np.array_equal(prev, want_prev)
+
+
+def test_group_transport_selection(scene_dir):
+    from cosc_4397_pathtracing_raytracing_project_amd import capi
+    sc = capi.Scene(scene_dir["cornell"], res=(64, 48))
+    with pytest.raises(capi.PtError, match="listed twice"):
+        capi.Group(sc, [0, 0], transport="rccl")
+    g = capi.Group(sc, [0], transport="auto")
+    try:
+        assert g.transport == "rccl"  # distinct devices: RCCL stays the default
+    finally:
+        g.free()
+    ref, _ = single(scene_dir["cornell"], (64, 48), 3)
+    g = capi.Group(capi.Scene(scene_dir["cornell"], res=(64, 48)), [0, 0, 0, 0, 0], transport="copy")
+    try:
+        g.render(1, 3)
+        assert np.array_equal(g.gather().view(np.uint32), ref.view(np.uint32))
+    finally:
+        g.free()
+
+
+def test_pt_render_device_list_on_one_gpu(scene_dir, tmp_path):
+    """`pt_render --devices 0,0,0`: the C++ multi-device driver with three contexts on the one card."""
+    outs = {}
+    for tag, extra in (("shim", []), ("d3", ["--devices", "0,0,0"]), ("d2p", ["--devices", "0,0", "--preview", "4"])):
+        out = str(tmp_path / tag)
+        p = subprocess.run([BIN, scene_dir["cornell"], "--res", "160x121", "--spp", "10", "--out", out, "--pfm"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr + p.stdout
+        outs[tag] = (open(f"{out}.10samp.png", "rb").read(), open(f"{out}.10samp.pfm", "rb").read())
+    assert outs["d3"] == outs["shim"] and outs["d2p"] == outs["shim"]
+    assert os.path.exists(str(tmp_path / "d2p") + ".preview.png")
+    p = subprocess.run([BIN, scene_dir["cornell"], "--devices", "0,0", "--transport", "rccl"], capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and "listed twice" in p.stderr
+
+
 def test_group_progressive_preview(scene_dir, tmp_path):
     """pt_group_preview_rgba8 (sendImageToPBO on every device + one exchange) equals the single-context preview, can be
     taken between batches without disturbing the accumulation, and `pt_render --gpus K --preview N` writes the file."""

@@ -309,15 +309,16 @@ def test_c5_stress_scene_rows_bit_exact(oracle, tmp_path):
     sc = capi.Scene(path, res=(w, h))
     assert sc.desc.num_geoms == 10170 and len(sc.bvh()) == 20339
     imgs = []
-    for flags in (0, 512):
+    for flags in (0, 256, 512):  # the library's own (timed) choice, grid forced, grid forbidden
         r = capi.Renderer(sc, debug_flags=flags)
         r.render(1, spp)
         imgs.append(r.readback())
-        assert (r.stats().grid_cells > 0) == (flags == 0)
+        if flags:  # which structure flags == 0 picks is a timing decision at pt_init: only its IMAGE is asserted
+            assert (r.stats().grid_cells > 0) == (flags == 256)
         r.free()
     img = imgs[0]
     assert np.isfinite(img).all()
-    assert np.array_equal(bits(imgs[0]), bits(imgs[1]))
+    assert np.array_equal(bits(imgs[0]), bits(imgs[1])) and np.array_equal(bits(imgs[0]), bits(imgs[2]))
     oracle.set_math_mode(oracle.PORTABLE)
     oracle.load_scene(path, res=(w, h))
     for row in (300, 540, 900):

@@ -38,6 +38,24 @@ def test_loader_matches_oracle_and_counts_objects(oracle, mesh_scene):
     assert len(quad) == 2 and all(n.bmax[2] > n.bmin[2] for n in quad)
 
 
+def test_mesh_block_without_tri_lines_loads_like_the_reference_loader(oracle, tmp_path):
+    """A reference-format file can say `mesh` (INSTRUCTION.md:246) but cannot contain TRI lines — those are this build's
+    own syntax.  Such a block must load as the reference's loader leaves it (scene.cpp:47-55: no type assigned, ONE geom
+    pushed): one geom, the initial type, the following objects' ids and indices unshifted."""
+    text = scenes.cornell_scene_text(res=(32, 32))
+    text += "OBJECT 7\nmesh\nmaterial 2\nTRANS 1 2 3\nROTAT 0 45 0\nSCALE 2 2 2\n\n"
+    text += "OBJECT 8\ncube\nmaterial 3\nTRANS -1 1 0\nROTAT 0 0 0\nSCALE 1 1 1\n\n"
+    path = scenes.write_scene(text, str(tmp_path / "m.txt"))
+    sc = capi.Scene(path)
+    oracle.load_scene(path)
+    geoms = sc.geoms()
+    assert sc.desc.num_geoms == len(oracle.geoms()) == 9
+    assert geoms[7].type == 0 and geoms[7].materialid == 2 and geoms[8].type == 1 and geoms[8].materialid == 3
+    assert all(bytes(a) == bytes(b) for a, b in zip(geoms, oracle.geoms()))
+    m, i, it = capi.build_transform([1, 2, 3, 0, 45, 0, 2, 2, 2])
+    assert np.array_equal(np.frombuffer(bytes(geoms[7].transform), np.float32), m)
+
+
 def test_triangle_test_is_glm_intersect_ray_triangle(oracle, mesh_scene):
     """The quad faces +z (towards the camera): rays from the front hit it at z = -3 with normal (0, 0, 1); rays from behind
     pass through (front faces only, like glm::intersectRayTriangle); rays beside it miss."""
