@@ -442,11 +442,8 @@ ptk::SceneTables tables(const Ctx& g) {
 
 int alloc_pathbuf(Ctx& g, ptd::PathBuf* b, int64_t stride) {
   b->stride = stride;
-  if (dalloc(g, &b->o, 3 * stride)) return -1;
-  if (dalloc(g, &b->d, 3 * stride)) return -1;
-  if (dalloc(g, &b->c, 3 * stride)) return -1;
-  if (dalloc(g, &b->slot, stride)) return -1;
-  return 0;
+  // planes 0 and 1: 16 bytes per path, plane 2: kPathPlane2Bytes (pt_device.h); allocated in 16-byte words
+  return dalloc(g, &b->r, 2 * stride + (stride * ptd::kPathPlane2Bytes + 15) / 16);
 }
 int alloc_hitbuf(Ctx& g, ptd::HitBuf* h, int64_t stride) {
   h->stride = stride;
@@ -1038,6 +1035,41 @@ int pt_reset_stats(void) { return pt_ctx_reset_stats(g_default); }
 int pt_clear(void) { return pt_ctx_clear(g_default); }
 
 // ---- stage entry points (tests; default context) ------------------------------------------------
+// The C ABI of the stages takes plain SoA float arrays ([3][n]); the kernels stream three planes of 16-byte path records
+// (ptd::PathBuf), so the stage wrappers pack / unpack on the host.
+namespace {
+struct StagePaths {
+  ptd::PathBuf pb{};
+  std::vector<ptd::Word4> host;
+  size_t cap = 0;
+  bool alloc(Scratch& sc, size_t cap_) {
+    cap = cap_;
+    pb.stride = (int64_t)cap;
+    pb.r = sc.get<ptd::Word4>(3 * cap);
+    host.assign(3 * cap, ptd::Word4{0.f, 0.f, 0.f, 0.f});
+    return pb.r != nullptr;
+  }
+  void pack(int n, const float* o, const float* d, const float* c) {  // arrays are [3][n]; null = zeros
+    for (int i = 0; i < n; ++i) {
+      auto at = [&](const float* a, int k) { return a ? a[(size_t)k * n + i] : 0.0f; };
+      host[i] = ptd::Word4{at(o, 0), at(o, 1), at(o, 2), at(d, 0)};
+      host[cap + i] = ptd::Word4{at(d, 1), at(d, 2), at(c, 0), at(c, 1)};
+      reinterpret_cast<float*>(&host[2 * cap])[(size_t)i * (ptd::kPathPlane2Bytes / 4)] = at(c, 2);
+    }
+  }
+  int upload() { return hipMemcpy(pb.r, host.data(), host.size() * sizeof(ptd::Word4), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1; }
+  int download() { return hipMemcpy(host.data(), pb.r, host.size() * sizeof(ptd::Word4), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
+  void unpack(int n, float* o, float* d, float* c) const {
+    for (int i = 0; i < n; ++i) {
+      const ptd::Word4 &w0 = host[i], &w1 = host[cap + i];
+      const float cz = reinterpret_cast<const float*>(&host[2 * cap])[(size_t)i * (ptd::kPathPlane2Bytes / 4)];
+      if (o) o[i] = w0.x, o[(size_t)n + i] = w0.y, o[2 * (size_t)n + i] = w0.z;
+      if (d) d[i] = w0.w, d[(size_t)n + i] = w1.x, d[2 * (size_t)n + i] = w1.y;
+      if (c) c[i] = w1.z, c[(size_t)n + i] = w1.w, c[2 * (size_t)n + i] = cz;
+    }
+  }
+};
+}  // namespace
 
 int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
   if (need(g_default, "pt_stage_generate")) return -1;
@@ -1046,23 +1078,17 @@ int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
   HIP_OK(hipSetDevice(g.device));
   Scratch sc;
   ptd::Queues qs = single_queue(g, n);
-  ptd::PathBuf pb{};
-  pb.stride = qs.cap;
-  pb.o = sc.get<float>(3 * (size_t)qs.cap);
-  pb.d = sc.get<float>(3 * (size_t)qs.cap);
-  pb.c = sc.get<float>(3 * (size_t)qs.cap);
-  pb.slot = sc.get<int32_t>(qs.cap);
+  StagePaths sp;
   int32_t* cnt = sc.get<int32_t>(16);
-  if (!pb.o || !pb.d || !pb.c || !pb.slot || !cnt) return fail("pt_stage_generate: out of device memory");
+  if (!sp.alloc(sc, (size_t)qs.cap) || !cnt) return fail("pt_stage_generate: out of device memory");
+  const ptd::PathBuf pb = sp.pb;
   ptk::BatchInfo b{};
   b.iter_first = 1, b.K = 1, b.N = n, b.pixel_begin = pix_begin, b.trace_depth = g.depth;
   b.aa_jitter = g.aa_jitter ? 1 : 0;
   g.k->generate(g.stream, g.grid, g.dcam, b, qs, pb, cnt);
   HIP_OK(hipStreamSynchronize(g.stream));
-  for (int c = 0; c < 3; ++c) {
-    HIP_OK(hipMemcpy(origin + (size_t)c * n, pb.o + (size_t)c * qs.cap, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(dir + (size_t)c * n, pb.d + (size_t)c * qs.cap, (size_t)n * 4, hipMemcpyDeviceToHost));
-  }
+  if (sp.download()) return fail("pt_stage_generate: download failed");
+  sp.unpack(n, origin, dir, nullptr);
   return 0;
 }
 
@@ -1075,10 +1101,9 @@ int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, f
   Scratch sc;
   ptd::Queues qs = single_queue(g, n);
   const size_t cap = qs.cap;
-  ptd::PathBuf pb{};
-  pb.stride = cap;
-  pb.o = sc.get<float>(3 * cap);
-  pb.d = sc.get<float>(3 * cap);
+  StagePaths sp;
+  const bool have_paths = sp.alloc(sc, cap);
+  const ptd::PathBuf pb = sp.pb;
   ptd::HitBuf hb{};
   hb.stride = cap;
   hb.t = sc.get<float>(cap);
@@ -1086,11 +1111,9 @@ int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, f
   hb.mat = sc.get<int32_t>(cap);
   hb.p = sc.get<float>(3 * cap);
   int32_t* cnt = sc.get<int32_t>(16);
-  if (!pb.o || !pb.d || !hb.t || !hb.n || !hb.mat || !hb.p || !cnt) return fail("pt_stage_intersect: out of device memory");
-  for (int c = 0; c < 3; ++c) {
-    HIP_OK(hipMemcpy(pb.o + c * cap, origin + (size_t)c * n, (size_t)n * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(pb.d + c * cap, dir + (size_t)c * n, (size_t)n * 4, hipMemcpyHostToDevice));
-  }
+  if (!have_paths || !hb.t || !hb.n || !hb.mat || !hb.p || !cnt) return fail("pt_stage_intersect: out of device memory");
+  sp.pack(n, origin, dir, nullptr);
+  if (sp.upload()) return fail("pt_stage_intersect: upload failed");
   HIP_OK(hipMemcpy(cnt, &n, 4, hipMemcpyHostToDevice));
   g.k->intersect(g.stream, g.grid, tables(g), qs, cnt, pb, hb, g.legacy, false);
   HIP_OK(hipStreamSynchronize(g.stream));
@@ -1116,11 +1139,9 @@ int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, 
   HIP_OK(hipSetDevice(g.device));
   Scratch sc;
   const size_t cap = n;
-  ptd::PathBuf pb{};
-  pb.stride = cap;
-  pb.o = sc.get<float>(3 * cap);
-  pb.d = sc.get<float>(3 * cap);
-  pb.c = sc.get<float>(3 * cap);
+  StagePaths sp;
+  const bool have_paths = sp.alloc(sc, cap);
+  const ptd::PathBuf pb = sp.pb;
   ptd::HitBuf hb{};
   hb.stride = cap;
   hb.t = sc.get<float>(cap);
@@ -1130,12 +1151,11 @@ int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, 
   int32_t* d_iter = sc.get<int32_t>(cap);
   int32_t* d_pix = sc.get<int32_t>(cap);
   int32_t* d_alive = sc.get<int32_t>(cap);
-  if (!pb.o || !pb.d || !pb.c || !hb.t || !hb.n || !hb.mat || !hb.p || !d_iter || !d_pix || !d_alive)
+  if (!have_paths || !hb.t || !hb.n || !hb.mat || !hb.p || !d_iter || !d_pix || !d_alive)
     return fail("pt_stage_shade: out of device memory");
   const size_t b1 = (size_t)n * 4, b3 = 3 * b1;
-  HIP_OK(hipMemcpy(pb.o, origin, b3, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(pb.d, dir, b3, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(pb.c, color, b3, hipMemcpyHostToDevice));
+  sp.pack(n, origin, dir, color);
+  if (sp.upload()) return fail("pt_stage_shade: upload failed");
   HIP_OK(hipMemcpy(hb.t, t, b1, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(hb.n, normal, b3, hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(hb.mat, material, b1, hipMemcpyHostToDevice));
@@ -1144,9 +1164,8 @@ int pt_stage_shade(int n, int depth, const int32_t* iter, const int32_t* pixel, 
   HIP_OK(hipMemcpy(d_pix, pixel, b1, hipMemcpyHostToDevice));
   g.k->shade_stage(g.stream, tables(g), g.depth, depth, n, d_iter, d_pix, hb, pb, d_alive);
   HIP_OK(hipStreamSynchronize(g.stream));
-  HIP_OK(hipMemcpy(origin, pb.o, b3, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(dir, pb.d, b3, hipMemcpyDeviceToHost));
-  HIP_OK(hipMemcpy(color, pb.c, b3, hipMemcpyDeviceToHost));
+  if (sp.download()) return fail("pt_stage_shade: download failed");
+  sp.unpack(n, origin, dir, color);
   HIP_OK(hipMemcpy(alive, d_alive, b1, hipMemcpyDeviceToHost));
   return 0;
 }

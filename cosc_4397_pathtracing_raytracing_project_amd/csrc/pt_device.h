@@ -1,9 +1,9 @@
 // pt_device.h — device-side data layout of the MI355X wavefront path tracer.
 //
-// Everything the kernels stream is structure-of-arrays with 4-byte scalars so
-// that a wave64 access is one contiguous 256-B run per plane (the reference's
-// PathSegment is 44-B AoS and ShadeableIntersection 40-B AoS,
-// src/sceneStructs.h:69-83).  Scene tables are tiny, read-only, and staged into LDS.
+// Everything the kernels stream is structure-of-arrays — planes of 16-byte words for the path state (PathBuf), 4-byte
+// scalars for the hit records of the unfused form — so that a wave64 access is one contiguous run per plane (the
+// reference's PathSegment is 44-B AoS and ShadeableIntersection 40-B AoS, src/sceneStructs.h:69-83).  Scene tables are
+// tiny, read-only, and staged into LDS.
 #pragma once
 #include <stdint.h>
 
@@ -73,13 +73,25 @@ struct Camera {
   float pl_x, pl_y;
 };
 
-// Ray / path state planes.  A path occupies the same index in every plane.
+// Ray / path state: three planes of 16-byte words, a path occupying the same index in each, so that a wave64 access is
+// one contiguous 1-KB run per plane and a path costs three loads / three stores (round 1-2: ten 4-byte planes, i.e. ten
+// memory instructions and ten 64-bit address computations each way; the kernels are bound by instruction issue):
+//   plane 0   origin.xyz, direction.x
+//   plane 1   direction.yz, colour.xy
+//   plane 2   colour.z | slot: sample id inside the batch, k*N + p (k = iteration in batch, p = tile pixel) |
+//             utilhash(global pixel index): the per-pixel half of makeSeededRandomEngine's seed (pathtrace.cu:205), computed
+//             once per sample at depth 0 instead of once per ray and depth | k
+// 48 B per path (40 B of algorithmic state + the carried hash and iteration: 8 B that save a division and a hash per bounce).
+struct alignas(16) Word4 {
+  float x, y, z, w;
+};
+#ifndef PT_REC_TAGGED
+#define PT_REC_TAGGED 0
+#endif
+constexpr int kPathPlane2Bytes = PT_REC_TAGGED ? 16 : 8;  // plane 2 without the carried hash / iteration: colour.z, slot
 struct PathBuf {
-  float* o;      // [3][stride] origin
-  float* d;      // [3][stride] direction
-  float* c;      // [3][stride] throughput colour
-  int32_t* slot; // [stride]    sample id inside the batch: k*N + p  (k = iteration in batch, p = tile pixel)
-  int64_t stride;
+  Word4* r;        // planes 0 and 1 at r, r + stride; plane 2 (kPathPlane2Bytes per path) at r + 2 * stride
+  int64_t stride;  // paths per plane
 };
 // Hit records (the 32 live bytes of ShadeableIntersection).
 struct HitBuf {

@@ -270,6 +270,83 @@ PT_DEV int global_pixel(const BatchInfo& b, int p) {
   return b.pixel_begin + p + i * b.gap;
 }
 
+// ───────────────────────────── path records (ptd::PathBuf) ─────────────────
+// What rides along with a path besides its ray and colour: the sample id and — PT_REC_TAGGED builds only — the per-pixel
+// half of the RNG seed and the iteration inside the batch (so that no depth has to divide the sample id or hash the pixel
+// index again: -56 VALU per 64-ray group, +8 B per path each way).
+#ifndef PT_REC_TAGGED
+#define PT_REC_TAGGED 0
+#endif
+constexpr bool kTagged = PT_REC_TAGGED != 0;
+static_assert(kTagged == (ptd::kPathPlane2Bytes == 16), "pt_device.h and PT_REC_TAGGED disagree about plane 2");
+struct PathTag {
+  int slot;
+  uint32_t phash;  // utilhash(global pixel index)                                   (kTagged)
+  int k;           // iteration inside the batch: iteration = BatchInfo::iter_first + k   (kTagged)
+};
+struct PathRec {
+  f3 o, d, c;
+  PathTag tag;
+};
+struct alignas(8) Word2 {
+  float x, y;
+};
+// plane 2: colour.z, slot [, pixel hash, k]
+PT_DEV void plane2_load(const ptd::PathBuf& b, int64_t at, float& cz, PathTag& tag) {
+  if constexpr (kTagged) {
+    const ptd::Word4 w2 = b.r[2 * b.stride + at];
+    cz = w2.x;
+    tag.slot = __float_as_int(w2.y), tag.phash = __float_as_uint(w2.z), tag.k = __float_as_int(w2.w);
+  } else {
+    const Word2 w2 = reinterpret_cast<const Word2*>(b.r + 2 * b.stride)[at];
+    cz = w2.x;
+    tag.slot = __float_as_int(w2.y), tag.phash = 0u, tag.k = 0;
+  }
+}
+PT_DEV void plane2_store(const ptd::PathBuf& b, int64_t at, float cz, const PathTag& tag) {
+  if constexpr (kTagged) b.r[2 * b.stride + at] = ptd::Word4{cz, __int_as_float(tag.slot), __uint_as_float(tag.phash), __int_as_float(tag.k)};
+  else reinterpret_cast<Word2*>(b.r + 2 * b.stride)[at] = Word2{cz, __int_as_float(tag.slot)};
+}
+PT_DEV void path_load_ray(const ptd::PathBuf& b, int64_t at, f3& o, f3& d) {  // planes 0, 1
+  const ptd::Word4 w0 = b.r[at], w1 = b.r[b.stride + at];
+  o = mk(w0.x, w0.y, w0.z);
+  d = mk(w0.w, w1.x, w1.y);
+}
+PT_DEV void path_load_tail(const ptd::PathBuf& b, int64_t at, f3& d, f3& c, PathTag& tag) {  // planes 1, 2 + direction.x
+  const ptd::Word4 w1 = b.r[b.stride + at];
+  float cz;
+  plane2_load(b, at, cz, tag);
+  d = mk(reinterpret_cast<const float*>(b.r + at)[3], w1.x, w1.y);
+  c = mk(w1.z, w1.w, cz);
+}
+PT_DEV PathRec path_load(const ptd::PathBuf& b, int64_t at) {
+  const ptd::Word4 w0 = b.r[at], w1 = b.r[b.stride + at];
+  PathRec v;
+  float cz;
+  plane2_load(b, at, cz, v.tag);
+  v.o = mk(w0.x, w0.y, w0.z);
+  v.d = mk(w0.w, w1.x, w1.y);
+  v.c = mk(w1.z, w1.w, cz);
+  return v;
+}
+PT_DEV void path_store(const ptd::PathBuf& b, int64_t at, f3 o, f3 d, f3 c, const PathTag& tag) {
+  b.r[at] = ptd::Word4{o.x, o.y, o.z, d.x};
+  b.r[b.stride + at] = ptd::Word4{d.y, d.z, c.x, c.y};
+  plane2_store(b, at, c.z, tag);
+}
+// makeSeededRandomEngine's seed (pathtrace.cu:205) of a path at `depth`: utilhash((1 << 31) | depth << 22 | iteration) ^
+// utilhash(global pixel index).  The first factor comes from the per-block table (iter_hash_of); the second rides along
+// with the path (kTagged) or is recomputed from the sample id.
+PT_DEV uint32_t path_seed(const PathTag& tag, const uint32_t* ihash, const SceneTables& sc, const BatchInfo& b, int depth, float inv_n) {
+  if constexpr (kTagged) {
+    return iter_hash_of(ihash, sc, b, depth, tag.k) ^ tag.phash;
+  } else {
+    int k, p;
+    divmod(tag.slot, b.N, inv_n, k, p);
+    return iter_hash_of(ihash, sc, b, depth, k) ^ utilhash((uint32_t)global_pixel(b, p));
+  }
+}
+
 // ───────────────────────────── generate ────────────────────────────────────
 __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo b, ptd::Queues qs, ptd::PathBuf out,
                                                      int32_t* __restrict__ cnt0) {
@@ -288,7 +365,6 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
     }
     cnt0[(size_t)q * qs.cnt_stride] = (int32_t)n;
   }
-  const int64_t S = out.stride;
   for (long long j = r; j < my_chunks; j += wq) {
     const long long gid = (j * qs.Q + q) * 64 + lane;
     if (gid < total) {
@@ -299,10 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
       if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
       const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
       const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
-      out.o[at] = cam.pos[0], out.o[S + at] = cam.pos[1], out.o[2 * S + at] = cam.pos[2];
-      out.d[at] = d.x, out.d[S + at] = d.y, out.d[2 * S + at] = d.z;
-      out.c[at] = 1.0f, out.c[S + at] = 1.0f, out.c[2 * S + at] = 1.0f;
-      out.slot[at] = (int32_t)gid;
+      path_store(out, at, mk(cam.pos[0], cam.pos[1], cam.pos[2]), d, mk(1.0f, 1.0f, 1.0f), PathTag{(int)gid, utilhash((uint32_t)p), k});
     }
   }
 }
@@ -453,13 +526,13 @@ __global__ __launch_bounds__(kBlock) void k_intersect_legacy(SceneTables sc, ptd
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t S = paths.stride, HS = hits.stride;
+  const int64_t HS = hits.stride;
   for (int j = r; j * 64 < n_q; j += wq) {
     const int i = j * 64 + lane;
     if (i < n_q) {
       const int64_t at = (int64_t)q * qs.cap + i;
-      const f3 o = mk(paths.o[at], paths.o[S + at], paths.o[2 * S + at]);
-      const f3 d = mk(paths.d[at], paths.d[S + at], paths.d[2 * S + at]);
+      f3 o, d;
+      path_load_ray(paths, at, o, d);
       const HitRec h = trace<EX>(nodes, sc.num_nodes, geoms, o, d);
       const bool hit = h.geom >= 0;
       // record layout of the reference after its per-depth memset (pathtrace.cu:562):
@@ -679,7 +752,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t S = paths.stride, HS = hits.stride;
+  const int64_t HS = hits.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
   // Memory operations are kept branch-free so that the compiler can count them (s_waitcnt vmcnt(N)
   // is in-order): every lane of a group loads and stores, lanes past the queue's fill level touch the
@@ -688,21 +761,13 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
   // (software pipeline): their HBM latency overlaps ~1k instructions of work.
   const int last = qs.cap - 64 + lane;  // clamp for the prefetch beyond the last group
   f3 no, nd;
-  {
-    const int64_t a0 = qbase + min(r * 64 + lane, last);
-    no = mk(paths.o[a0], paths.o[S + a0], paths.o[2 * S + a0]);
-    nd = mk(paths.d[a0], paths.d[S + a0], paths.d[2 * S + a0]);
-  }
+  path_load_ray(paths, qbase + min(r * 64 + lane, last), no, nd);
   for (int j = r; j * 64 < n_q; j += wq) {
     const int i = j * 64 + lane;
     const bool valid = i < n_q;
     const int64_t at = qbase + i;
     const f3 o = no, d = nd;
-    {
-      const int64_t an = qbase + min((j + wq) * 64 + lane, last);
-      no = mk(paths.o[an], paths.o[S + an], paths.o[2 * S + an]);
-      nd = mk(paths.d[an], paths.d[S + an], paths.d[2 * S + an]);
-    }
+    path_load_ray(paths, qbase + min((j + wq) * 64 + lane, last), no, nd);
     trace_group<false, false, EX>(w, top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, nullptr, sc.has_triangles != 0);
 
     const unsigned long long best = w.best[lane];
@@ -752,8 +817,8 @@ struct Bounce {
   int kind;         // 0 none, 1 specular, 2 diffuse
   float roughness;
 };
-PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, uint32_t ihash, int pixel,
-                           float ht, int hmat, ShadeIO& s) {  // ihash = iter_hash(iteration, depth)
+PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, uint32_t seed, float ht, int hmat,
+                           ShadeIO& s) {  // seed = iter_hash(iteration, depth) ^ utilhash(global pixel index), pathtrace.cu:205
   Bounce bo;
   bo.kind = 0;
   bo.rng_x = 1u;
@@ -764,7 +829,7 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
     for (int k = depth; k < trace_depth; ++k) s.c = mul(s.c, sky);
     return bo;
   }
-  MinStd rng(ihash ^ utilhash((uint32_t)pixel));
+  MinStd rng(seed);
   const ptd::Mat* m = mats + hmat;
   const f3 mcolor = mk(m->color[0], m->color[1], m->color[2]);
   if (m->emittance > 0.0f) {
@@ -874,25 +939,24 @@ PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int slot, fl
                                       int32_t* __restrict__ counter, int lane) {
   // one 16-B store per retired sample: retirements are scattered over the batch, and three 4-B stores into three
   // planes dirtied three partially filled lines per sample (PMC round 1: 59 B written per 12 B retired)
+#if defined(PT_ABL_NO_RETIRE)  // timing experiments only (wrong images): no retirement store / a coalesced one
+  (void)final_rgba;
+#elif defined(PT_ABL_RETIRE_SEQ)
+  if (valid && !s.alive) final_rgba[(blockIdx.x * kBlock + threadIdx.x) + 1024 * 256 * ((slot >> 4) & 31)] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
+#else
   if (valid && !s.alive) final_rgba[slot] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
+#endif
   Reservation r;
   r.live = __ballot(valid && s.alive);
   r.base = 0;
   if (r.live && lane == 0) r.base = atomicAdd(counter, __popcll(r.live));
   return r;
 }
-PT_DEV void emit_survivors(const Reservation& r, bool alive, const ShadeIO& s, int slot, int64_t qbase, ptd::PathBuf out) {
+PT_DEV void emit_survivors(const Reservation& r, bool alive, const ShadeIO& s, const PathTag& tag, int64_t qbase, ptd::PathBuf out) {
   if (r.live) {
     const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(r.live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)r.live, 0));
     const int base = __builtin_amdgcn_readfirstlane(r.base);
-    if (alive) {
-      const int64_t OS = out.stride;
-      const int64_t to = qbase + base + rank;
-      out.o[to] = s.o.x, out.o[OS + to] = s.o.y, out.o[2 * OS + to] = s.o.z;
-      out.d[to] = s.d.x, out.d[OS + to] = s.d.y, out.d[2 * OS + to] = s.d.z;
-      out.c[to] = s.c.x, out.c[OS + to] = s.c.y, out.c[2 * OS + to] = s.c.z;
-      out.slot[to] = slot;
-    }
+    if (alive) path_store(out, qbase + base + rank, s.o, s.d, s.c, tag);
   }
 }
 
@@ -902,12 +966,12 @@ PT_DEV void emit_survivors(const Reservation& r, bool alive, const ShadeIO& s, i
 struct Deferred {
   Reservation res;
   ShadeIO s;
-  int slot;
+  PathTag tag;
   bool alive;
   bool any;  // wave-uniform: survivors pending
 };
 PT_DEV void flush_deferred(Deferred& df, int64_t qbase, ptd::PathBuf out) {
-  if (df.any) emit_survivors(df.res, df.alive, df.s, df.slot, qbase, out);
+  if (df.any) emit_survivors(df.res, df.alive, df.s, df.tag, qbase, out);
   df.any = false;
 }
 
@@ -926,13 +990,14 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t S = in.stride, HS = hits.stride;
+  const int64_t HS = hits.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
   // inputs of one path; the next group's are loaded (branch-free, index clamped into the queue's own
   // region) while the current group is shaded
   struct In {
-    int slot, hmat;
+    PathTag tag;
+    int hmat;
     float ht;
     f3 hn, hp, d, c;
   };
@@ -940,13 +1005,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   auto load = [&](int i) {
     In v;
     const int64_t at = qbase + min(i, last);
-    v.slot = in.slot[at];
     v.ht = hits.t[at];
     v.hn = mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]);
     v.hmat = hits.mat[at];
     v.hp = mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]);
-    v.d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
-    v.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
+    path_load_tail(in, at, v.d, v.c, v.tag);
     return v;
   };
   In nx = load(r * 64 + lane);
@@ -960,18 +1023,13 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     s.d = cur.d;
     s.c = cur.c;
     s.alive = false;
-    const int slot = cur.slot;
     Bounce bo;
     bo.kind = 0;
-    if (valid) {
-      int k, p;
-      divmod(slot, b.N, inv_n, k, p);
-      bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, sc, b, depth, k), global_pixel(b, p), cur.ht, cur.hmat, s);
-    }
-    const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    if (valid) bo = shade_decide(mats, b.trace_depth, depth, path_seed(cur.tag, ihash, sc, b, depth, inv_n), cur.ht, cur.hmat, s);
+    const Reservation res = retire_and_reserve(valid, s, cur.tag.slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, cur.hn, cur.hp, s);
-    emit_survivors(res, alive, s, slot, qbase, out);
+    emit_survivors(res, alive, s, cur.tag, qbase, out);
   }
 }
 
@@ -1372,7 +1430,7 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
 // State of a group between its search and its shading (one loop iteration later).
 struct Pending {
   f3 d, c;
-  int slot;
+  PathTag tag;
   bool valid;
   int par, mark;
   bool any;  // wave-uniform: a group is pending
@@ -1403,15 +1461,13 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
       hn = mk(r[0 * 64], r[1 * 64], r[2 * 64]);
       hp = mk(r[3 * 64], r[4 * 64], r[5 * 64]);
     }
-    int k, p;
-    divmod(pg.slot, b.N, inv_n, k, p);
-    bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, sc, b, depth, k), global_pixel(b, p), ht, hmat, s);
+    bo = shade_decide(mats, b.trace_depth, depth, path_seed(pg.tag, ihash, sc, b, depth, inv_n), ht, hmat, s);
   }
-  df.res = retire_and_reserve(pg.valid, s, pg.slot, final_rgba, counter, lane);
+  df.res = retire_and_reserve(pg.valid, s, pg.tag.slot, final_rgba, counter, lane);
   const bool alive = pg.valid && s.alive;
   if (alive && !(kAblate && (b.debug & 8))) shade_bounce(bo, hn, hp, s);
   df.s = s;
-  df.slot = pg.slot;
+  df.tag = pg.tag;
   df.alive = alive;
   df.any = df.res.live != 0;
 }
@@ -1514,6 +1570,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     int k, pl;
     divmod(slot, b.N, inv_n, k, pl);
     const int p = global_pixel(b, pl);  // global pixel index
+    const uint32_t phash = utilhash((uint32_t)p);  // rides along with the path from here on (PathTag)
     float jx = 0.f, jy = 0.f;
     if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
     const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
@@ -1555,13 +1612,13 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
         hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
         if (GRID) hn = Ar<kD0>::finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
       }
-      bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k), p, ht, hmat, s);
+      bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
     }
     df.res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
     df.s = s;
-    df.slot = slot;
+    df.tag = PathTag{slot, phash, k};
     df.alive = alive;
     df.any = df.res.live != 0;
   }
@@ -1610,27 +1667,14 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t S = in.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
-  struct In {
-    f3 o, d, c;
-    int slot;
-  };
   const int last = qs.cap - 64 + lane;  // branch-free loads, clamped into the queue's own region
-  auto load = [&](int i) {
-    In v;
-    const int64_t at = qbase + min(i, last);
-    v.o = mk(in.o[at], in.o[S + at], in.o[2 * S + at]);
-    v.d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
-    v.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
-    v.slot = in.slot[at];
-    return v;
-  };
-  In nx = load(r * 64 + lane);
+  auto load = [&](int i) { return path_load(in, qbase + min(i, last)); };
+  PathRec nx = load(r * 64 + lane);
 #define PT_TOUCH_PREFETCH()                                                                                         \
   asm volatile("" ::"v"(nx.o.x), "v"(nx.o.y), "v"(nx.o.z), "v"(nx.d.x), "v"(nx.d.y), "v"(nx.d.z), "v"(nx.c.x), "v"(nx.c.y), \
-               "v"(nx.c.z), "v"(nx.slot))
+               "v"(nx.c.z), "v"(nx.tag.slot), "v"(nx.tag.phash), "v"(nx.tag.k))
   PT_TOUCH_PREFETCH();  // same wait point as inside the loop, so that the loop header needs no vector-memory wait
   Pending pg;
   pg.any = false;
@@ -1641,7 +1685,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   for (int j = r; j * 64 < n_q; j += wq, ++it) {
     const int i = j * 64 + lane;
     const bool valid = i < n_q;
-    const In cur = nx;
+    const PathRec cur = nx;
     nx = load((j + wq) * 64 + lane);  // next group's paths in flight while this group is searched
     const int par = it & 1;
     cy.best[par * 64 + lane] = kNoHit;
@@ -1657,7 +1701,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
     if (pg.any) shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
     pg.d = cur.d;
     pg.c = cur.c;
-    pg.slot = cur.slot;
+    pg.tag = cur.tag;
     pg.valid = valid;
     pg.par = par;
     pg.mark = cy.appended;
@@ -1711,7 +1755,6 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t S = in.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
   const int last = qs.cap - 64 + lane;
@@ -1721,20 +1764,20 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
     const bool valid = i < n_q;
     const int64_t at = qbase + min(i, last);
     {
-      const f3 o = mk(in.o[at], in.o[S + at], in.o[2 * S + at]);
-      const f3 d = mk(in.d[at], in.d[S + at], in.d[2 * S + at]);
+      f3 o, d;
+      path_load_ray(in, at, o, d);
       cy.best[lane] = kNoHit;
       if (GRID) grid_search<1>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
       else carry_search<true, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
     }
     while (cy.count > 0) carry_chunk<false, 1, false, GRID>(cy, min(64, cy.count), lane, nodes, geoms);
-    // shade: direction from the wave's LDS ray buffer, colour and slot from memory
+    // shade: direction, colour and tag re-read from memory (planes 1 and 2; the search needed the registers)
     ShadeIO s;
     s.o = mk(0.f, 0.f, 0.f);
-    s.d = mk(cy.ray[3 * 64 + lane], cy.ray[4 * 64 + lane], cy.ray[5 * 64 + lane]);
-    s.c = mk(in.c[at], in.c[S + at], in.c[2 * S + at]);
+    PathTag tag;
+    path_load_tail(in, at, s.d, s.c, tag);
     s.alive = false;
-    const int slot = in.slot[at];
+    const int slot = tag.slot;
     const unsigned long long best = cy.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
     Bounce bo;
@@ -1751,14 +1794,12 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
         hp = mk(cy.rec[3 * 64 + lane], cy.rec[4 * 64 + lane], cy.rec[5 * 64 + lane]);
         if (GRID) hn = finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
       }
-      int k, p;
-      divmod(slot, b.N, inv_n, k, p);
-      bo = shade_decide(mats, b.trace_depth, depth, iter_hash_of(ihash, sc, b, depth, k), global_pixel(b, p), ht, hmat, s);
+      bo = shade_decide(mats, b.trace_depth, depth, path_seed(tag, ihash, sc, b, depth, inv_n), ht, hmat, s);
     }
     const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, counter, lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
-    emit_survivors(res, alive, s, slot, qbase, out);
+    emit_survivors(res, alive, s, tag, qbase, out);
   }
 }
 
@@ -1771,20 +1812,19 @@ __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trac
   stage16(lds_raw, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
   __syncthreads();
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds_raw);
-  const int64_t S = paths.stride, HS = hits.stride;
+  const int64_t HS = hits.stride;
   for (int at = blockIdx.x * blockDim.x + threadIdx.x; at < n; at += gridDim.x * blockDim.x) {
+    const PathRec pr = path_load(paths, at);
     ShadeIO s;
-    s.o = mk(paths.o[at], paths.o[S + at], paths.o[2 * S + at]);
-    s.d = mk(paths.d[at], paths.d[S + at], paths.d[2 * S + at]);
-    s.c = mk(paths.c[at], paths.c[S + at], paths.c[2 * S + at]);
+    s.o = pr.o;
+    s.d = pr.d;
+    s.c = pr.c;
     s.alive = false;
-    const Bounce bo = shade_decide(mats, trace_depth, depth, iter_hash(iter[at], depth), pixel[at], hits.t[at], hits.mat[at], s);
+    const Bounce bo = shade_decide(mats, trace_depth, depth, iter_hash(iter[at], depth) ^ utilhash((uint32_t)pixel[at]), hits.t[at], hits.mat[at], s);
     // the stage reports the bounce ray whenever one is sampled (also at the last depth), like the reference
     if (bo.kind) shade_bounce(bo, mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]),
                               mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]), s);
-    paths.o[at] = s.o.x, paths.o[S + at] = s.o.y, paths.o[2 * S + at] = s.o.z;
-    paths.d[at] = s.d.x, paths.d[S + at] = s.d.y, paths.d[2 * S + at] = s.d.z;
-    paths.c[at] = s.c.x, paths.c[S + at] = s.c.y, paths.c[2 * S + at] = s.c.z;
+    path_store(paths, at, s.o, s.d, s.c, pr.tag);
     alive[at] = s.alive ? 1 : 0;
   }
 }
