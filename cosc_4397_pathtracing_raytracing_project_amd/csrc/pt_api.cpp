@@ -109,7 +109,7 @@ struct PtContext {
   int grid_primary = 0, grid_bounce = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
-  float4* d_final = nullptr;
+  ptd::RetireBuf ret{};  // retirement records + fill levels (pt_device.h)
   float* d_image = nullptr;
   uint8_t* d_rgb8 = nullptr;  // lazily allocated output of pt_ctx_save_u8
   int32_t* d_cnt = nullptr;
@@ -480,7 +480,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   if (g.fuse_primary) {
     // depth 0 in one launch; its survivors are the depth-1 input (buf[1], cnt[1])
     k.primary(g.stream, g.grid_primary, sc, g.dcam, b, queues_for(g, g.grid_primary), g.d_cnt, g.d_cnt + per_depth, g.buf[1],
-              g.d_final);
+              g.ret);
     d0 = 1;
   } else {
     k.generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g, g.grid_gen), g.buf[0], g.d_cnt);
@@ -495,7 +495,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
     }
     if (g.fuse_bounces) {
       k.bounce(g.stream, g.grid_bounce, sc, b, d, queues_for(g, g.grid_bounce), cin, cout, g.buf[d & 1], g.buf[(d + 1) & 1],
-               g.d_final);
+               g.ret);
     } else {
       k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy, d == 0);
     }
@@ -505,10 +505,23 @@ int run_batch(Ctx& g, int iter_first, int kb) {
     }
     if (!g.fuse_bounces)
       k.shade(g.stream, g.grid_shade, sc, b, d, queues_for(g, g.grid_shade), cin, cout, g.buf[d & 1], g.hits, g.buf[(d + 1) & 1],
-              g.d_final);
+              g.ret);
+  }
+  if (getenv("PT_DUMP_QUEUE_BALANCE")) {  // diagnostics: fill levels of the queues per depth (before k_count_stats zeroes them)
+    HIP_OK(hipStreamSynchronize(g.stream));
+    std::vector<int32_t> h((size_t)(g.depth + 1) * per_depth);
+    HIP_OK(hipMemcpy(h.data(), g.d_cnt, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int d = 0; d <= g.depth; ++d) {
+      double sum = 0, mx = 0, mn = 1e30;
+      for (int q = 0; q < g.qs.Q; ++q) {
+        const double v = h[(size_t)d * per_depth + (size_t)q * g.qs.cnt_stride];
+        sum += v, mx = std::max(mx, v), mn = std::min(mn, v);
+      }
+      std::fprintf(stderr, "queue balance depth %d: mean %.0f min %.0f max %.0f (max/mean %.3f)\n", d, sum / g.qs.Q, mn, mx, sum > 0 ? mx / (sum / g.qs.Q) : 0.0);
+    }
   }
   k.count_stats(g.stream, g.qs, g.d_cnt, g.depth, g.d_stats);
-  k.gather(g.stream, b, g.d_final, g.d_image);
+  k.collect(g.stream, b, g.qs, g.ret, g.d_image);
   HIP_OK(hipGetLastError());
   g.samples += (int64_t)kb * g.N;
   if (g.pending_isect.size() > 16384) {
@@ -580,6 +593,8 @@ ptd::Queues single_queue(const Ctx& g, int n) {
   qs.cap = ((n + 63) / 64) * 64;
   qs.W = g.grid * ptk::kWavesPerBlock;
   qs.cnt_stride = 16;
+  qs.nq = (n + 63) / 64;
+  qs.inv_nq = 1.0f / (float)qs.nq;
   return qs;
 }
 
@@ -654,22 +669,36 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
     K = (int)std::max<int64_t>(1, std::min<int64_t>(256, (target + g.N - 1) / g.N));
   }
   while ((int64_t)K * g.N > (1ll << 30) && K > 1) --K;
-  g.K = K;
 
-  // Compaction queues: every launch needs (waves % Q) == 0, so Q divides 4 * CUs.
+  // Compaction queues: every launch needs (waves % Q) == 0, so Q divides 4 * CUs.  A queue owns every Q-th 64-pixel
+  // chunk of the tile in every iteration (pt_device.h); k_collect wants at most 128 chunks per queue (one LDS tile per
+  // pass), so large tiles get more queues while the waves allow it.
   int Q = opt.num_queues > 0 ? opt.num_queues : 256;
   const int cu_waves = g.num_cus * ptk::kWavesPerBlock;
   if (Q > cu_waves) Q = cu_waves;
   while (cu_waves % Q) --Q;
+  const int64_t chunks = ((int64_t)g.N + 63) / 64;  // per iteration
+  if (opt.num_queues <= 0)
+    while ((chunks + Q - 1) / Q > 128 && 2 * Q <= cu_waves && cu_waves % (2 * Q) == 0) Q *= 2;
+  const int nq = (int)((chunks + Q - 1) / Q);
   const int grid = g.num_cus * 8;
+  // Retirement records: one private segment per (queue, iteration of the batch, wave of the queue), each able to hold all
+  // of the queue's pixels (pt_device.h RetireBuf): samples * R * 16 bytes.  HBM is there to be used (288 GB), but keep the
+  // default batch within ~48 GB of records.
+  const int R = std::max(1, grid * ptk::kWavesPerBlock / Q);
+  while (K > 1 && (int64_t)K * Q * nq * 64 * R * 16 > (48ll << 30)) --K;
+  g.K = K;
   g.grid = grid;
   g.qs.Q = Q;
   g.qs.W = grid * ptk::kWavesPerBlock;
   g.qs.cnt_stride = 16;
-  const int64_t total = (int64_t)K * g.N;
-  const int64_t chunks = (total + 63) / 64;
-  g.qs.cap = (int)(((chunks + Q - 1) / Q) * 64);
+  g.qs.nq = nq;
+  g.qs.inv_nq = 1.0f / (float)nq;
+  g.qs.cap = K * nq * 64;
   g.stride = (int64_t)Q * g.qs.cap;
+  g.ret.seg_cap = nq * 64;
+  g.ret.R = R;
+  g.ret.kmax = K;
 
   // scene tables
   std::vector<PtBVHNode> ref_nodes;
@@ -757,7 +786,12 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   // path state
   if (alloc_pathbuf(g, &g.buf[0], g.stride) || alloc_pathbuf(g, &g.buf[1], g.stride)) return -1;
   if (!g.fuse_bounces && alloc_hitbuf(g, &g.hits, g.stride)) return -1;  // hit records reach HBM only in the unfused form
-  if (dalloc(g, &g.d_final, (size_t)total) || dalloc(g, &g.d_image, 3 * (size_t)g.N)) return -1;
+  {
+    const size_t segs = (size_t)Q * g.ret.R * g.ret.kmax;
+    if (dalloc(g, &g.ret.rec, segs * g.ret.seg_cap) || dalloc(g, &g.ret.cnt, segs)) return -1;
+    HIP_OK(hipMemset(g.ret.cnt, 0, segs * sizeof(int32_t)));  // k_collect re-zeroes what it consumed after every batch
+  }
+  if (dalloc(g, &g.d_image, 3 * (size_t)g.N)) return -1;
   if (dalloc(g, &g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;
   HIP_OK(hipMemset(g.d_cnt, 0, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride * sizeof(int32_t)));  // k_count_stats re-zeroes it after every batch
   if (dalloc(g, &g.d_stats, PT_MAX_DEPTH)) return -1;

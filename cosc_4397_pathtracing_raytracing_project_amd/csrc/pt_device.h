@@ -102,17 +102,45 @@ struct HitBuf {
   int64_t stride;
 };
 
+// Retirement records.  A sample's final colour is known when its path dies — at any depth, in whatever order compaction
+// has left the paths in — while finalGather (pathtrace.cu:439-444) needs, per pixel, the colours of its K samples in
+// iteration order.  Rounds 1-2 stored each colour at final[k*N + p]: one scattered 16-byte write per sample, each a
+// partially written DRAM line — a third of the bounce kernel's time at K = 25 (round 3 ablation).  Now:
+//   * a queue owns the SAME pixel chunks in every iteration (Queues, below), i.e. a fixed set of nq*64 pixels;
+//   * a retiring lane appends the record (r, g, b, tile pixel index) to a segment that belongs to (queue q, iteration k,
+//     wave r of the queue's waves) alone — consecutive lanes to consecutive addresses, no atomics: the segment's fill
+//     level is a counter private to that wave (kept in LDS during a kernel, in `cnt` between kernels);
+//   * k_collect, one workgroup per queue, reads the segments of (q, k) for k = 0, 1, ... (coalesced), drops the colours
+//     into an LDS tile indexed by pixel, and adds the tile to the queue's pixels — the reference's summation order.
+// Every sample retires exactly once, so segment (q, k, *) fill levels add up to the queue's pixel count; a segment can
+// hold all of them (seg_cap = nq * 64).
+struct RetireBuf {
+  Word4* rec;       // [Q][R][kmax][seg_cap]
+  int32_t* cnt;     // [Q][R][kmax] fill levels (zero between batches: k_collect resets what it consumed)
+  int32_t seg_cap;  // nq * 64: pixels a queue owns
+  int32_t R;        // waves per queue the segments are provisioned for (>= W / Q of every launch)
+  int32_t kmax;     // iterations per batch the segments are provisioned for
+  int32_t pad;
+};
+
 // Work distribution.  Paths live in Q independent queues of capacity `cap`
 // (queue q owns indices [q*cap, (q+1)*cap) of every plane).  The persistent grid has
 // W waves; wave w serves queue w % Q together with the other W/Q - 1 waves of that
 // queue, taking 64-path groups round-robin.  Survivors of a shading pass are appended
 // to the same queue of the other PathBuf through one atomicAdd per wave on the
 // queue's counter, so counters are spread over Q cache lines.
+// Samples are dealt to the queues in 64-pixel chunks: chunk g of the tile (pixels 64 g .. 64 g + 63) belongs to queue
+// g % Q in EVERY iteration (rounds 1-2 dealt the chunks of the whole batch round-robin, so a queue saw different pixels
+// in every iteration); queue q's sample sequence is iteration-major: entry j = k * nq + jj is chunk q + jj * Q of
+// iteration k, nq = ceil(chunks / Q).  A queue thus samples the frame on a regular lattice (every Q-th chunk), which
+// balances the queues' work to within a few per cent without any dependence on the iteration.
 struct Queues {
   int32_t Q;
   int32_t cap;
   int32_t W;            // total waves in the grid (multiple of Q)
   int32_t cnt_stride;   // ints between consecutive queue counters (64-B padding)
+  int32_t nq;           // chunks per queue and iteration: ceil(ceil(N / 64) / Q)
+  float inv_nq;         // 1.0f / nq (divmod)
 };
 
 }  // namespace ptd

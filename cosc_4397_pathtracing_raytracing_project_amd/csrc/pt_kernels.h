@@ -94,10 +94,10 @@ struct KernelApi {
   // Depth 0 fused (generate + intersect + shade + compaction): survivors go to `out` / cnt_out (the depth-1
   // queues), retired samples to final_rgba; cnt0 receives the per-queue sample counts (statistics only).
   void (*primary)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
-                  const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float4* final_rgba);
+                  const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf ret);
   // Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.
   void (*bounce)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
-                 const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba);
+                 const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret);
   // computeIntersections over the live paths of every queue.  exact_arith: these are primary rays (depth 0), which
   // are traced with the reference's exact arithmetic in every mode (pt_kernels.hip, namespace ex).
   void (*intersect)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
@@ -105,9 +105,10 @@ struct KernelApi {
   // shadeAndExtendRays + compaction + retirement.
   void (*shade)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                 const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                float4* final_rgba /* [K*N] one record per sample */);
-  // finalGather: image[p] += final[0][p] + final[1][p] + ... in iteration order.
-  void (*gather)(hipStream_t s, const BatchInfo& b, const float4* final_rgba, float* image_rgb /* [N][3] */);
+                ptd::RetireBuf ret);
+  // finalGather: image[p] += colour of sample (0, p) + (1, p) + ... in iteration order, from the retirement records
+  // (ptd::RetireBuf); also resets the records' fill levels for the next batch.
+  void (*collect)(hipStream_t s, const BatchInfo& b, const ptd::Queues& qs, ptd::RetireBuf ret, float* image_rgb /* [N][3] */);
   // live-ray bookkeeping: stats[d] += sum_q cnt[d][q]
   void (*count_stats)(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count, unsigned long long* stats);
   // sendImageToPBO (pathtrace.cu:250-268)

@@ -334,17 +334,88 @@ PT_DEV void path_store(const ptd::PathBuf& b, int64_t at, f3 o, f3 d, f3 c, cons
   b.r[b.stride + at] = ptd::Word4{d.y, d.z, c.x, c.y};
   plane2_store(b, at, c.z, tag);
 }
+// Iteration (inside the batch) and tile pixel of a path: carried (kTagged) or from the sample id k * N + pl.
+PT_DEV void sample_of(const PathTag& tag, const BatchInfo& b, float inv_n, int& k, int& pl) {
+  divmod(tag.slot, b.N, inv_n, k, pl);
+  if constexpr (kTagged) k = tag.k;
+}
 // makeSeededRandomEngine's seed (pathtrace.cu:205) of a path at `depth`: utilhash((1 << 31) | depth << 22 | iteration) ^
 // utilhash(global pixel index).  The first factor comes from the per-block table (iter_hash_of); the second rides along
-// with the path (kTagged) or is recomputed from the sample id.
-PT_DEV uint32_t path_seed(const PathTag& tag, const uint32_t* ihash, const SceneTables& sc, const BatchInfo& b, int depth, float inv_n) {
-  if constexpr (kTagged) {
-    return iter_hash_of(ihash, sc, b, depth, tag.k) ^ tag.phash;
-  } else {
-    int k, p;
-    divmod(tag.slot, b.N, inv_n, k, p);
-    return iter_hash_of(ihash, sc, b, depth, k) ^ utilhash((uint32_t)global_pixel(b, p));
+// with the path (kTagged) or is recomputed from the tile pixel.
+PT_DEV uint32_t path_seed(const PathTag& tag, int k, int pl, const uint32_t* ihash, const SceneTables& sc, const BatchInfo& b, int depth) {
+  const uint32_t ph = kTagged ? tag.phash : utilhash((uint32_t)global_pixel(b, pl));
+  return iter_hash_of(ihash, sc, b, depth, k) ^ ph;
+}
+
+// ───────────────────────────── retirement records (ptd::RetireBuf) ─────────
+// Per-wave state: the wave's own segments (queue q, iteration k, wave r of the queue) and their fill levels, which live
+// in LDS while the kernel runs (loaded by retire_begin, written back by retire_end: nobody else touches them).
+struct Retire {
+  ptd::Word4* seg;  // records of segment (q, 0, r); segment (q, k, r) starts k * seg_cap records further
+  int* fill;        // LDS [K]
+  int seg_cap;
+  // The iteration the wave appended to last, its segment and fill level, wave-uniform in registers: consecutive groups of
+  // a wave are neighbours in the queue's iteration-major order, so almost every append hits it and touches LDS not at all
+  // (with the fill level read from LDS per append the dependent LDS round trip cost 13 % of the bounce kernel).
+  int ck, cfill;
+  ptd::Word4* cseg;
+};
+__host__ __device__ inline int retire_wave_bytes(const SceneTables& sc) { return (sc.max_batch_iters * 4 + 15) & ~15; }
+__host__ __device__ inline int retire_lds_bytes(const SceneTables& sc) { return kWavesPerBlock * retire_wave_bytes(sc); }
+PT_DEV Retire retire_begin(void* lds_base, const ptd::RetireBuf& rb, const SceneTables& sc, const BatchInfo& b, int q, int r, int wib, int lane) {
+  Retire rt;
+  rt.fill = reinterpret_cast<int*>(reinterpret_cast<char*>(lds_base) + wib * retire_wave_bytes(sc));
+  const int64_t s0 = ((int64_t)q * rb.R + r) * rb.kmax;
+  rt.seg = rb.rec + s0 * rb.seg_cap;
+  rt.seg_cap = rb.seg_cap;
+  rt.ck = -1, rt.cfill = 0, rt.cseg = rt.seg;
+  for (int k = lane; k < b.K; k += 64) rt.fill[k] = rb.cnt[s0 + k];
+  return rt;
+}
+PT_DEV void retire_end(const Retire& rt, const ptd::RetireBuf& rb, const BatchInfo& b, int q, int r, int lane) {
+  if (rt.ck >= 0 && lane == 0) rt.fill[rt.ck] = rt.cfill;
+  const int64_t s0 = ((int64_t)q * rb.R + r) * rb.kmax;
+  for (int k = lane; k < b.K; k += 64) rb.cnt[s0 + k] = rt.fill[k];
+}
+// The lanes with `dead` append (colour, tile pixel index) to the wave's segment of their iteration k: one 16-byte store per
+// lane, consecutive lanes to consecutive records.  The loop runs once per distinct iteration among the dead lanes: once,
+// rarely twice.  Wave-uniform control flow.
+PT_DEV void retire_append(Retire& rt, bool dead, int k, int pl, f3 c, int lane) {
+#ifdef PT_ABL_NO_RETIRE  // timing experiment only (wrong images)
+  return;
+#endif
+  unsigned long long m = __ballot(dead);
+  while (m) {
+    const int k0 = __builtin_amdgcn_readlane(k, (int)__builtin_ctzll(m));
+    const bool mine = dead && k == k0;
+    const unsigned long long mk = __ballot(mine);
+    if (k0 != rt.ck) {  // another iteration than last time: park the cached fill level, fetch this one's
+      if (rt.ck >= 0 && lane == 0) rt.fill[rt.ck] = rt.cfill;
+      rt.ck = k0;
+      rt.cfill = __builtin_amdgcn_readfirstlane(rt.fill[k0]);
+      rt.cseg = rt.seg + (int64_t)k0 * rt.seg_cap;
+    }
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0));
+    if (mine) rt.cseg[rt.cfill + rank] = ptd::Word4{c.x, c.y, c.z, __int_as_float(pl)};
+    rt.cfill += __popcll(mk);
+    m &= ~mk;
   }
+}
+// Queue q's share of an iteration (ptd::Queues): chunks q, q + Q, ... of the tile's ceil(N / 64); only the tile's last
+// chunk can be partial, and it is the last chunk of the queue that owns it.
+struct QueueShare {
+  int my_nq;      // chunks of this queue per iteration
+  int my_pixels;  // pixels of this queue per iteration
+  float inv_my_nq;
+};
+PT_DEV QueueShare queue_share(const BatchInfo& b, const ptd::Queues& qs, int q) {
+  const int chunks = (b.N + 63) >> 6;
+  QueueShare sh;
+  sh.my_nq = q < chunks ? (chunks - q + qs.Q - 1) / qs.Q : 0;
+  const int last_q = (chunks - 1) % qs.Q;
+  sh.my_pixels = sh.my_nq * 64 - ((q == last_q && (b.N & 63)) ? 64 - (b.N & 63) : 0);
+  sh.inv_my_nq = sh.my_nq > 0 ? 1.0f / (float)sh.my_nq : 0.0f;
+  return sh;
 }
 
 // ───────────────────────────── generate ────────────────────────────────────
@@ -353,29 +424,21 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const float inv_n = 1.0f / (float)b.N, inv_w = 1.0f / (float)cam.res_x;
-  const long long total = (long long)b.K * b.N;
-  const long long chunks = (total + 63) / 64;           // 64-sample chunks, dealt round-robin to queues
-  const long long my_chunks = (chunks - q + qs.Q - 1) / qs.Q;  // chunks q, q+Q, ...
-  if (r == 0 && lane == 0) {
-    long long n = 0;
-    if (my_chunks > 0) {
-      const long long last = q + (my_chunks - 1) * qs.Q;  // global id of my last chunk
-      n = (my_chunks - 1) * 64 + (last == chunks - 1 ? total - last * 64 : 64);
-    }
-    cnt0[(size_t)q * qs.cnt_stride] = (int32_t)n;
-  }
-  for (long long j = r; j < my_chunks; j += wq) {
-    const long long gid = (j * qs.Q + q) * 64 + lane;
-    if (gid < total) {
-      int k, pl;
-      divmod((int)gid, b.N, inv_n, k, pl);
+  const float inv_w = 1.0f / (float)cam.res_x;
+  const QueueShare sh = queue_share(b, qs, q);
+  if (r == 0 && lane == 0) cnt0[(size_t)q * qs.cnt_stride] = b.K * sh.my_pixels;
+  const int entries = b.K * sh.my_nq;  // iteration-major: entry j = k * my_nq + jj is chunk q + jj * Q of iteration k
+  for (int j = r; j < entries; j += wq) {
+    int k, jj;
+    divmod(j, sh.my_nq, sh.inv_my_nq, k, jj);
+    const int pl = (q + jj * qs.Q) * 64 + lane;  // tile pixel
+    if (pl < b.N) {
       const int p = global_pixel(b, pl);  // global pixel index
       float jx = 0.f, jy = 0.f;
       if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
       const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
-      const int64_t at = (int64_t)q * qs.cap + j * 64 + lane;
-      path_store(out, at, mk(cam.pos[0], cam.pos[1], cam.pos[2]), d, mk(1.0f, 1.0f, 1.0f), PathTag{(int)gid, utilhash((uint32_t)p), k});
+      const int64_t at = (int64_t)q * qs.cap + (int64_t)k * sh.my_pixels + jj * 64 + lane;  // dense: a partial chunk is the queue's last
+      path_store(out, at, mk(cam.pos[0], cam.pos[1], cam.pos[2]), d, mk(1.0f, 1.0f, 1.0f), PathTag{k * b.N + pl, utilhash((uint32_t)p), k});
     }
   }
 }
@@ -935,17 +998,10 @@ struct Reservation {
   unsigned long long live;
   int base;
 };
-PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int slot, float4* __restrict__ final_rgba,
-                                      int32_t* __restrict__ counter, int lane) {
-  // one 16-B store per retired sample: retirements are scattered over the batch, and three 4-B stores into three
-  // planes dirtied three partially filled lines per sample (PMC round 1: 59 B written per 12 B retired)
-#if defined(PT_ABL_NO_RETIRE)  // timing experiments only (wrong images): no retirement store / a coalesced one
-  (void)final_rgba;
-#elif defined(PT_ABL_RETIRE_SEQ)
-  if (valid && !s.alive) final_rgba[(blockIdx.x * kBlock + threadIdx.x) + 1024 * 256 * ((slot >> 4) & 31)] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
-#else
-  if (valid && !s.alive) final_rgba[slot] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
-#endif
+PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int k, int pl, Retire& rt, int32_t* __restrict__ counter, int lane) {
+  // dead lanes: one 16-byte record each, appended to the wave's own segment of iteration k (retire_append) — rounds 1-2
+  // scattered them over final[k * N + p], a partial DRAM line per sample
+  retire_append(rt, valid && !s.alive, k, pl, s.c, lane);
   Reservation r;
   r.live = __ballot(valid && s.alive);
   r.base = 0;
@@ -978,17 +1034,19 @@ PT_DEV void flush_deferred(Deferred& df, int64_t qbase, ptd::PathBuf out) {
 __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                   const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
                                                   ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                                                  float4* __restrict__ final_rgba) {
+                                                  ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
-  stage16(lds_raw, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_raw) + ((sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15));
+  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // [retirement fill levels][materials][iteration hashes]
+  stage16(lds, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + ((sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15));
   iter_hash_fill(ihash, sc, b, depth);
   __syncthreads();
-  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds_raw);
+  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds);
 
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, threadIdx.x >> 6, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t HS = hits.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
@@ -1025,12 +1083,15 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     s.alive = false;
     Bounce bo;
     bo.kind = 0;
-    if (valid) bo = shade_decide(mats, b.trace_depth, depth, path_seed(cur.tag, ihash, sc, b, depth, inv_n), cur.ht, cur.hmat, s);
-    const Reservation res = retire_and_reserve(valid, s, cur.tag.slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    int k, pl;
+    sample_of(cur.tag, b, inv_n, k, pl);
+    if (valid) bo = shade_decide(mats, b.trace_depth, depth, path_seed(cur.tag, k, pl, ihash, sc, b, depth), cur.ht, cur.hmat, s);
+    const Reservation res = retire_and_reserve(valid, s, k, pl, rt, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, cur.hn, cur.hp, s);
     emit_survivors(res, alive, s, cur.tag, qbase, out);
   }
+  retire_end(rt, ret, b, q, r, lane);
 }
 
 // ── candidate ring with carry-over (fused kernels) ────────────────────────────────────────
@@ -1439,7 +1500,7 @@ struct Pending {
 template <bool SMALL>
 PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
                           const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
-                          int depth, float inv_n, float4* __restrict__ final_rgba,
+                          int depth, float inv_n, Retire& rt,
                           int32_t* __restrict__ counter, Deferred& df, int lane) {
   const unsigned long long best = cy.best[pg.par * 64 + lane];
   const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1451,6 +1512,8 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
   Bounce bo;
   bo.kind = 0;
   f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+  int k, pl;
+  sample_of(pg.tag, b, inv_n, k, pl);
   if (pg.valid) {
     float ht = -1.0f;
     int hmat = 0;
@@ -1461,9 +1524,9 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
       hn = mk(r[0 * 64], r[1 * 64], r[2 * 64]);
       hp = mk(r[3 * 64], r[4 * 64], r[5 * 64]);
     }
-    bo = shade_decide(mats, b.trace_depth, depth, path_seed(pg.tag, ihash, sc, b, depth, inv_n), ht, hmat, s);
+    bo = shade_decide(mats, b.trace_depth, depth, path_seed(pg.tag, k, pl, ihash, sc, b, depth), ht, hmat, s);
   }
-  df.res = retire_and_reserve(pg.valid, s, pg.tag.slot, final_rgba, counter, lane);
+  df.res = retire_and_reserve(pg.valid, s, k, pl, rt, counter, lane);
   const bool alive = pg.valid && s.alive;
   if (alive && !(kAblate && (b.debug & 8))) shade_bounce(bo, hn, hp, s);
   df.s = s;
@@ -1484,9 +1547,9 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
 template <bool TABLES_IN_LDS, bool GRID = false>
 __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
                                                     int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
-                                                    ptd::PathBuf out, float4* __restrict__ final_rgba) {
+                                                    ptd::PathBuf out, ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw);
+  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // the retirement fill levels come first
   static_assert(!(GRID && TABLES_IN_LDS), "the grid walk reads the tables from memory");
   const int nb_top = GRID ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
@@ -1546,31 +1609,25 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  // samples are dealt to the queues in 64-sample chunks, round-robin (same map as k_generate)
-  const long long total = (long long)b.K * b.N;
-  const long long chunks = (total + 63) / 64;
-  const long long my_chunks = (chunks - q + qs.Q - 1) / qs.Q;
-  if (r == 0 && lane == 0) {
-    long long n = 0;
-    if (my_chunks > 0) {
-      const long long last = q + (my_chunks - 1) * qs.Q;
-      n = (my_chunks - 1) * 64 + (last == chunks - 1 ? total - last * 64 : 64);
-    }
-    cnt0[(size_t)q * qs.cnt_stride] = (int32_t)n;
-  }
+  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
+  // the queue's samples, iteration-major: entry j = k * my_nq + jj is chunk q + jj * Q of iteration k (same map as k_generate)
+  const QueueShare sh = queue_share(b, qs, q);
+  if (r == 0 && lane == 0) cnt0[(size_t)q * qs.cnt_stride] = b.K * sh.my_pixels;
+  const int entries = b.K * sh.my_nq;
   const int64_t qbase = (int64_t)q * qs.cap;
-  const float inv_n = 1.0f / (float)b.N, inv_w = 1.0f / (float)cam.res_x;
+  const float inv_w = 1.0f / (float)cam.res_x;
   const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
   Deferred df;
   df.any = false;
-  for (long long j = r; j < my_chunks; j += wq) {
-    const long long gid = (j * qs.Q + q) * 64 + lane;
-    const bool valid = gid < total;
-    const int slot = (int)(valid ? gid : total - 1);
-    int k, pl;
-    divmod(slot, b.N, inv_n, k, pl);
+  for (int j = r; j < entries; j += wq) {
+    int k, jj;
+    divmod(j, sh.my_nq, sh.inv_my_nq, k, jj);
+    const int pl_raw = (q + jj * qs.Q) * 64 + lane;
+    const bool valid = pl_raw < b.N;
+    const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
+    const int slot = k * b.N + pl;
     const int p = global_pixel(b, pl);  // global pixel index
-    const uint32_t phash = utilhash((uint32_t)p);  // rides along with the path from here on (PathTag)
+    const uint32_t phash = utilhash((uint32_t)p);  // rides along with the path from here on (kTagged)
     float jx = 0.f, jy = 0.f;
     if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
     const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
@@ -1614,7 +1671,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
     }
-    df.res = retire_and_reserve(valid, s, slot, final_rgba, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    df.res = retire_and_reserve(valid, s, k, pl, rt, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
     df.s = s;
@@ -1623,6 +1680,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     df.any = df.res.live != 0;
   }
   flush_deferred(df, qbase, out);
+  retire_end(rt, ret, b, q, r, lane);
 }
 
 // ── depth >= 1 fused: computeIntersections + shadeAndExtendRays + compaction ───────────────
@@ -1635,9 +1693,9 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
 template <bool TABLES_IN_LDS>
 __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                    const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
-                                                   ptd::PathBuf in, ptd::PathBuf out, float4* __restrict__ final_rgba) {
+                                                   ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw);
+  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // the retirement fill levels come first
   const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
@@ -1666,6 +1724,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
@@ -1698,7 +1757,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
     // wait; the stores and the atomic below then have until the same point of the next iteration.
     PT_TOUCH_PREFETCH();
     flush_deferred(df, qbase, out);  // survivors of the group shaded one iteration ago
-    if (pg.any) shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
+    if (pg.any) shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, rt, counter, df, lane);
     pg.d = cur.d;
     pg.c = cur.c;
     pg.tag = cur.tag;
@@ -1710,9 +1769,10 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   flush_deferred(df, qbase, out);
   if (pg.any) {
     carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-    shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, final_rgba, counter, df, lane);
+    shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, rt, counter, df, lane);
     flush_deferred(df, qbase, out);
   }
+  retire_end(rt, ret, b, q, r, lane);
 }
 
 // ── depth >= 1 for scenes with subtrees below the top list (thousands of primitives) ────────────────
@@ -1729,9 +1789,9 @@ constexpr int kBigWaves = PT_BIG_WAVES;
 template <bool GRID>
 __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                                 const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
-                                                                ptd::PathBuf in, ptd::PathBuf out, float4* __restrict__ final_rgba) {
+                                                                ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw);
+  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // the retirement fill levels come first
   const int nb_top = GRID ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk replaces top list and subtrees
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
@@ -1754,6 +1814,7 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
@@ -1777,7 +1838,8 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
     PathTag tag;
     path_load_tail(in, at, s.d, s.c, tag);
     s.alive = false;
-    const int slot = tag.slot;
+    int k, pl;
+    sample_of(tag, b, inv_n, k, pl);
     const unsigned long long best = cy.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
     Bounce bo;
@@ -1794,13 +1856,14 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
         hp = mk(cy.rec[3 * 64 + lane], cy.rec[4 * 64 + lane], cy.rec[5 * 64 + lane]);
         if (GRID) hn = finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
       }
-      bo = shade_decide(mats, b.trace_depth, depth, path_seed(tag, ihash, sc, b, depth, inv_n), ht, hmat, s);
+      bo = shade_decide(mats, b.trace_depth, depth, path_seed(tag, k, pl, ihash, sc, b, depth), ht, hmat, s);
     }
-    const Reservation res = retire_and_reserve(valid, s, slot, final_rgba, counter, lane);
+    const Reservation res = retire_and_reserve(valid, s, k, pl, rt, counter, lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
     emit_survivors(res, alive, s, tag, qbase, out);
   }
+  retire_end(rt, ret, b, q, r, lane);
 }
 
 // test-only stage: explicit (iter, pixel) per path, in-place, no compaction
@@ -1830,26 +1893,119 @@ __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trac
 }
 
 // ───────────────────────────── gather / stats / preview ────────────────────
-__global__ __launch_bounds__(kBlock) void k_gather(BatchInfo b, const float4* __restrict__ final_rgba,
-                                                   float* __restrict__ image) {
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < b.N; p += gridDim.x * blockDim.x) {
-    float r = image[3 * (int64_t)p], g = image[3 * (int64_t)p + 1], bl = image[3 * (int64_t)p + 2];
-    // iteration order, like successive finalGather launches; loads are issued eight iterations at a time (eight
-    // 16-B records in flight per lane), the adds stay strictly sequential (float sums are order-dependent)
-    int k = 0;
-    for (; k + 8 <= b.K; k += 8) {
-      float4 v[8];
+// finalGather (pathtrace.cu:439-444) from the retirement records: one workgroup per queue.  The queue owns the same
+// pixels in every iteration (ptd::Queues), at most kCollectPixels of them per pass; for k = 0, 1, ... the records of
+// (q, k) — R private segments, read with coalesced 16-byte loads — are dropped into an LDS tile indexed by pixel, and
+// every thread adds the tile to the accumulators of its pixels: image[p] = (((image[p] + c_0) + c_1) + ...), the
+// order in which successive finalGather launches would have added them.  Nothing is scattered through memory: the
+// segments are read once front to back, the image is read and written once.  Queues with more pixels than a tile
+// (frames beyond 4K at Q = 256 .. 1024) take several passes over their records.
+constexpr int kCollectThreads = 1024, kCollectWaves = kCollectThreads / 64;
+constexpr int kCollectPPT = 8;                                // pixels per thread and pass
+constexpr int kCollectPixels = kCollectPPT * kCollectThreads;  // 8192 pixels = 128 chunks: 96 KB of LDS
+// the queue's fill levels are staged in LDS while they are few (R * kmax <= 8192: 32 KB), otherwise read from memory
+__host__ __device__ inline bool collect_stages_fill(const ptd::RetireBuf& ret) { return ret.R * ret.kmax <= 8192; }
+__host__ __device__ inline int collect_lds_bytes(const ptd::RetireBuf& ret) {
+  return kCollectPixels * 12 + (collect_stages_fill(ret) ? ((ret.R * ret.kmax * 4 + 15) & ~15) : 0);
+}
+// the first (up to) 512 records of a segment, eight per lane
+struct CollectChunk {
+  ptd::Word4 v[8];
+};
+PT_DEV void collect_load(const ptd::Word4* rec, int n, int i0, int lane, CollectChunk& c) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = final_rgba[(int64_t)(k + u) * b.N + p];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) r += v[u].x, g += v[u].y, bl += v[u].z;
-    }
-    for (; k < b.K; ++k) {
-      const float4 v = final_rgba[(int64_t)k * b.N + p];
-      r += v.x, g += v.y, bl += v.z;
-    }
-    image[3 * (int64_t)p] = r, image[3 * (int64_t)p + 1] = g, image[3 * (int64_t)p + 2] = bl;
+  for (int u = 0; u < 8; ++u) {
+    const int i = i0 + u * 64 + lane;
+    c.v[u] = rec[i < n ? i : (n > 0 ? n - 1 : 0)];
   }
+}
+PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int lane, int Q, float inv_q, int first, float* tile) {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int i = i0 + u * 64 + lane;
+    const int pl = __float_as_int(c.v[u].w);
+    int jj, qq;
+    divmod(pl >> 6, Q, inv_q, jj, qq);
+    const int li = jj * 64 + (pl & 63) - first;
+    if (i < n && li >= 0 && li < kCollectPixels) tile[3 * li] = c.v[u].x, tile[3 * li + 1] = c.v[u].y, tile[3 * li + 2] = c.v[u].z;
+  }
+}
+__global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Queues qs, ptd::RetireBuf ret, float* __restrict__ image) {
+  extern __shared__ float4 lds_raw[];
+  float* tile = reinterpret_cast<float*>(lds_raw);                  // [kCollectPixels][3]
+  int* fill = reinterpret_cast<int*>(tile + 3 * kCollectPixels);    // [R][kmax] fill levels of the queue's segments
+  const int q = blockIdx.x;
+  const int wib = threadIdx.x >> 6, lane = lane_id();
+  const QueueShare sh = queue_share(b, qs, q);
+  const float inv_q = 1.0f / (float)qs.Q;
+  const int64_t s_q = (int64_t)q * ret.R * ret.kmax;
+  const bool staged = collect_stages_fill(ret);
+  if (staged)
+    for (int i = threadIdx.x; i < ret.R * ret.kmax; i += kCollectThreads) fill[i] = ret.cnt[s_q + i];
+  __syncthreads();
+  auto fill_of = [&](int r, int k) { return r < ret.R ? (staged ? fill[r * ret.kmax + k] : ret.cnt[s_q + r * ret.kmax + k]) : 0; };
+  // wave w reads the segments r = w and w + 16 of (q, k) (further ones, R > 32, without the prefetch)
+  const int r0 = wib, r1 = wib + kCollectWaves;
+  // (a wave without a segment, r >= R, is pointed at segment 0 and reads nothing of it: its fill level counts as 0)
+  const ptd::Word4* rec0 = ret.rec + (s_q + (int64_t)(r0 < ret.R ? r0 : 0) * ret.kmax) * ret.seg_cap;
+  const ptd::Word4* rec1 = ret.rec + (s_q + (int64_t)(r1 < ret.R ? r1 : 0) * ret.kmax) * ret.seg_cap;
+  for (int first = 0; first < sh.my_nq * 64; first += kCollectPixels) {  // one pass per kCollectPixels of the queue's pixels
+    float acc[kCollectPPT][3];
+    // thread t owns the queue pixels first + t + kCollectThreads * m: chunk jj = index >> 6 is tile chunk q + jj * Q
+#pragma unroll
+    for (int m = 0; m < kCollectPPT; ++m) {
+      const int li = first + threadIdx.x + kCollectThreads * m;
+      const int pl = (q + (li >> 6) * qs.Q) * 64 + (li & 63);
+      const bool mine = li < sh.my_nq * 64 && pl < b.N;
+      acc[m][0] = mine ? image[3 * (int64_t)pl] : 0.f, acc[m][1] = mine ? image[3 * (int64_t)pl + 1] : 0.f, acc[m][2] = mine ? image[3 * (int64_t)pl + 2] : 0.f;
+    }
+    // software pipeline: the first 512 records of the wave's two segments of iteration k + 1 are in flight while
+    // iteration k is summed (the tile is reused every iteration, so the two barriers per iteration stay)
+    CollectChunk c0, c1;
+    int n0 = fill_of(r0, 0), n1 = fill_of(r1, 0);
+    collect_load(rec0, n0, 0, lane, c0);
+    collect_load(rec1, n1, 0, lane, c1);
+    for (int k = 0; k < b.K; ++k) {
+      collect_scatter(c0, n0, 0, lane, qs.Q, inv_q, first, tile);
+      collect_scatter(c1, n1, 0, lane, qs.Q, inv_q, first, tile);
+      for (int i0 = 512; i0 < n0; i0 += 512) {  // segments longer than one chunk
+        collect_load(rec0 + (int64_t)k * ret.seg_cap, n0, i0, lane, c0);
+        collect_scatter(c0, n0, i0, lane, qs.Q, inv_q, first, tile);
+      }
+      for (int i0 = 512; i0 < n1; i0 += 512) {
+        collect_load(rec1 + (int64_t)k * ret.seg_cap, n1, i0, lane, c1);
+        collect_scatter(c1, n1, i0, lane, qs.Q, inv_q, first, tile);
+      }
+      for (int r = wib + 2 * kCollectWaves; r < ret.R; r += kCollectWaves) {  // R > 32 only
+        const int n = fill_of(r, k);
+        const ptd::Word4* rec = ret.rec + (s_q + (int64_t)r * ret.kmax + k) * ret.seg_cap;
+        for (int i0 = 0; i0 < n; i0 += 512) {
+          collect_load(rec, n, i0, lane, c0);
+          collect_scatter(c0, n, i0, lane, qs.Q, inv_q, first, tile);
+        }
+      }
+      if (k + 1 < b.K) {
+        n0 = fill_of(r0, k + 1), n1 = fill_of(r1, k + 1);
+        collect_load(rec0 + (int64_t)(k + 1) * ret.seg_cap, n0, 0, lane, c0);
+        collect_load(rec1 + (int64_t)(k + 1) * ret.seg_cap, n1, 0, lane, c1);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < kCollectPPT; ++m) {
+        const int li = threadIdx.x + kCollectThreads * m;  // every pixel of the queue retires exactly once per iteration: no stale entries are read
+        acc[m][0] += tile[3 * li], acc[m][1] += tile[3 * li + 1], acc[m][2] += tile[3 * li + 2];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < kCollectPPT; ++m) {
+      const int li = first + threadIdx.x + kCollectThreads * m;
+      const int pl = (q + (li >> 6) * qs.Q) * 64 + (li & 63);
+      if (li < sh.my_nq * 64 && pl < b.N) image[3 * (int64_t)pl] = acc[m][0], image[3 * (int64_t)pl + 1] = acc[m][1], image[3 * (int64_t)pl + 2] = acc[m][2];
+    }
+  }
+  // the records are consumed: empty segments for the next batch
+  for (int i = threadIdx.x; i < ret.R * ret.kmax; i += kCollectThreads) ret.cnt[s_q + i] = 0;
 }
 
 __global__ void k_count_stats(ptd::Queues qs, int32_t* __restrict__ cnt, int depth_count,
@@ -1915,7 +2071,7 @@ inline int round16(int x) { return (x + 15) & ~15; }
 
 // ───────────────────────────── launch wrappers ─────────────────────────────
 int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false) {
-  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
+  int bytes = retire_lds_bytes(sc) + sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
               iter_hash_entries(sc) * 4;
   if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
   if (primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + (in_lds ? round16(sc.num_geoms * 12) : 0);  // camera-relative copies
@@ -1925,13 +2081,13 @@ int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
 int big_lds_bytes(const SceneTables& sc) {
   if (sc.use_grid)
-    return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<false>() + iter_hash_entries(sc) * 4;
-  return sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * carry_bytes<false, 1>() +
+    return retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<false>() + iter_hash_entries(sc) * 4;
+  return retire_lds_bytes(sc) + sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * carry_bytes<false, 1>() +
          iter_hash_entries(sc) * 4;
 }
 bool use_big(const SceneTables& sc) { return sc.big_kernel != 0 && !tables_in_lds(sc); }
 int primary_grid_lds_bytes(const SceneTables& sc) {
-  return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<kD0>() + iter_hash_entries(sc) * 4;
+  return retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<kD0>() + iter_hash_entries(sc) * 4;
 }
 // The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
 bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
@@ -1983,7 +2139,7 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
       break;
     case kShade:
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
       break;
   }
   if (e != hipSuccess || n < 1) n = 1;
@@ -2015,14 +2171,14 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
 }
 
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
-                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, float4* final_rgba) {
+                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf final_rgba) {
   if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
   else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
 }
 
 void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
-                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, float4* final_rgba) {
+                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf final_rgba) {
   if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL(k_bounce_big<true>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
   else if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big<false>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
   else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, qs, cnt_in, cnt_out, in, out, final_rgba);
@@ -2031,8 +2187,8 @@ void launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchIn
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                  float4* final_rgba) {
-  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4;
+                  ptd::RetireBuf final_rgba) {
+  const int bytes = retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4;
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
                      final_rgba);
 }
@@ -2041,8 +2197,10 @@ int flat_grid(int n, int cap) {
   int grid = (n + kBlock - 1) / kBlock;
   return grid > cap ? cap : (grid < 1 ? 1 : grid);
 }
-void launch_gather(hipStream_t s, const BatchInfo& b, const float4* final_rgba, float* image_rgb) {
-  hipLaunchKernelGGL(k_gather, dim3(flat_grid(b.N, 4096)), dim3(kBlock), 0, s, b, final_rgba, image_rgb);
+void launch_collect(hipStream_t s, const BatchInfo& b, const ptd::Queues& qs, ptd::RetireBuf ret, float* image_rgb) {
+  // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking (per device: set on every launch, it is cheap)
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, collect_lds_bytes(ret));
+  hipLaunchKernelGGL(k_collect, dim3(qs.Q), dim3(kCollectThreads), collect_lds_bytes(ret), s, b, qs, ret, image_rgb);
 }
 
 void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count,
@@ -2073,7 +2231,7 @@ const KernelApi kApi = {
 #else
     "fast",
 #endif
-    launch_generate, launch_primary, launch_bounce, launch_intersect, launch_shade, launch_gather, launch_count_stats,
+    launch_generate, launch_primary, launch_bounce, launch_intersect, launch_shade, launch_collect, launch_count_stats,
     launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu};
 
 }  // namespace
