@@ -23,9 +23,11 @@ Extra objects on the JSON line:
                  timed region) vs 8 TB/s; `traffic` = HBM bytes per launch from the committed PMC passes
                  (profiles/dominant_kernel_traffic.json holds bytes PER RAY for this arithmetic mode) scaled by
                  this run's rays per launch.
-  roofline_valu  what actually bounds that kernel: vector-ALU instruction issue (one wave64 instruction per 4
-                 cycles per SIMD).  VALU instructions per 64-ray group and the pipe's busy fraction from the
-                 committed PMC summary, and the issue rate this run achieved against the 4-cycle peak.
+  roofline_valu  the kernel's instruction-issue ceiling: its dynamic VALU mix (committed PMC passes, SQ_INSTS_VALU_*
+                 per 64-ray group) priced at the MEASURED issue rates of tools/ubench_valu.hip (profiles/
+                 r03_ubench_valu.txt: f32 add / mul / fma 2.3-2.45 SIMD cycles per wave64 instruction, selects /
+                 compares / min / max / integer multiplies 4.2, transcendentals 8.2) against the SIMD cycles this run
+                 spent per group.  Unclassified instructions are priced at the full rate, so `frac` is a lower bound.
   cpu_baseline   the oracle (kind "port": oracle/pt_oracle.cpp, reference-literal loop, libm math)
                  timed on ONE host thread on a bounded sample of the same workload (rank 0, N=1 only).
   psnr           (N=1 only, outside the timed region) PSNR of 16/64/256/1000-spp prefixes against a 5000-spp
@@ -52,7 +54,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 ISECT_BYTES_PER_RAY = 56       # SURVEY.md §8(d), unfused computeIntersections
 REF_SPP = 5000                 # BASELINE: PSNR vs the 5000-spp image
 SIMDS_PER_CU = 4
-VALU_CYCLES_PER_WAVE_INSTR = 4  # wave64 on a 16-lane SIMD (non-packed f32 peak 78.6 TFLOP/s = 256 CUs x 4 x 16 x 2 x 2.4 GHz)
 
 
 def psnr(a: np.ndarray, b: np.ndarray) -> float:
@@ -222,19 +223,20 @@ def main() -> None:
                     "rays_per_launch": round(rays_per_launch, 1),
                     "depths_timed": "1..7 (depth 0 runs in the fused primary kernel)" if st.primary_fused else "0..7",
                     "live_rays_per_sample": round(float(live.sum()) / max(1, st.samples), 4)}
-        if same_kernel and "valu_per_group" in prof:
-            # measured bound: VALU issue.  groups/launch x VALU/group wave-instructions over (CUs x 4 SIMDs) in avg_us
-            groups = rays_per_launch / 64.0
-            rate = groups * prof["valu_per_group"] / (st.num_cus * SIMDS_PER_CU) / (avg_us * 1e-6)  # wave-instr/s/SIMD
-            clock = prof.get("shader_clock_ghz", 2.4) * 1e9
+        roofline["frac_56B"] = round(ISECT_BYTES_PER_RAY * units / isect_s / 1e9 / HBM_PEAK_GBS, 4)  # SURVEY §8(d)'s strict 56 B per live ray
+        if same_kernel and "valu_ceiling_simd_cycles_per_group" in prof:
+            # instruction-issue ceiling: SIMD cycles the measured mix needs per group vs SIMD cycles spent per group
+            groups_per_simd = rays_per_launch / 64.0 / (st.num_cus * SIMDS_PER_CU)
+            clock = (prof.get("shader_clock_ghz") or 2.1) * 1e9
+            spent = avg_us * 1e-6 * clock / groups_per_simd
+            need = prof["valu_ceiling_simd_cycles_per_group"]
             roofline_valu = {"bound": "valu", "kernel": kernel.split(" ")[0],
                              "valu_per_64ray_group": prof["valu_per_group"], "salu_per_64ray_group": prof.get("salu_per_group"),
-                             "valu_busy_frac_pmc": prof.get("valu_busy_frac"),
-                             "achieved": round(rate / 1e6, 1), "peak": round(clock / VALU_CYCLES_PER_WAVE_INSTR / 1e6, 1),
-                             "unit": "M wave-instructions/s per SIMD", "frac": round(rate / (clock / VALU_CYCLES_PER_WAVE_INSTR), 4),
-                             "source": f"profiles/dominant_kernel_traffic.json [{args.arith}] (PMC: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, "
-                                       f"SQ_BUSY_CYCLES) x this run's groups per launch / HIP-event time; peak = 1 wave64 "
-                                       f"instruction per {VALU_CYCLES_PER_WAVE_INSTR} cycles per SIMD at {clock / 1e9:.2f} GHz"}
+                             "valu_mix_per_64ray_group": prof.get("valu_mix_per_group"),
+                             "achieved": round(need, 1), "peak": round(spent, 1), "unit": "SIMD cycles per 64-ray group (needed by the VALU mix at measured issue rates / spent)",
+                             "frac": round(need / spent, 4), "shader_clock_ghz_pmc": prof.get("shader_clock_ghz"),
+                             "source": f"profiles/dominant_kernel_traffic.json [{args.arith}] (PMC: SQ_INSTS_VALU_* per group) priced with "
+                                       f"profiles/r03_ubench_valu.txt; unclassified instructions at the full rate: frac is a lower bound"}
 
     samples = float(W) * H * args.steps
     out = {
@@ -252,7 +254,7 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": f"cornell.txt 1920x1080, {args.steps} spp, depth 8, BVH + compaction, "
                                f"{world}x MI355X " + ("interleaved-row tiles" if striped else "row tiles") + (", one RCCL gather" if world > 1 else ""),
-                   "arith": args.arith,
+                   "arith": args.arith, "reference_equivalent_arith": "fma",
                    "iters_per_batch": int(st.iters_per_batch), "queues": int(st.num_queues),
                    "grid_blocks": int(st.grid_blocks), "cus": int(st.num_cus),
                    "device_mem_mb": round(st.device_bytes / 2 ** 20, 1),
@@ -265,14 +267,12 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_extras:
         img = full.cpu().numpy()
         r.free()
-        # ---- the other arithmetic modes, same process, same workload (bounded: <= 1000 steps each) ----
-        modes = {args.arith: {"value": out["value"], "steps": args.steps,
-                              "k_bounce_us": roofline["avg_launch_us"] if roofline else None,
-                              "hbm_frac": roofline["frac"] if roofline else None}}
-        msteps = min(args.steps, 1000)
+        # ---- all three arithmetic modes measured ALIKE, same process, same workload: a renderer of its own, 200 untimed
+        # steps, accumulation restarted, <= 1000 timed steps (`steady_value`).  The headline `value` stays what the
+        # driver's own --steps / --warmup measured; modes[headline].value repeats it.
+        modes = {}
+        msteps = min(max(args.steps, 200), 1000)
         for m in ("exact", "fma", "fast"):
-            if m in modes:
-                continue
             rr = make_renderer(True, arith=m)
             rr.render(1, 200)  # untimed; long enough for the memory the previous leg's renderer released to settle
             rr.readback_device(tile.data_ptr())
@@ -284,12 +284,19 @@ def main() -> None:
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
             s1 = rr.stats()
-            _, a1, _ = bounce_accounting(s1)
-            modes[m] = {"value": round(W * H * msteps / d1 / 1e6, 3), "steps": msteps,
+            _, a1, u1 = bounce_accounting(s1)
+            sv = round(W * H * msteps / d1 / 1e6, 3)
+            modes[m] = {"value": out["value"] if m == args.arith else sv, "steps": args.steps if m == args.arith else msteps,
+                        "steady_value": sv, "steady_steps": msteps,
                         "k_bounce_us": round(s1.intersect_ms * 1e3 / max(1, s1.intersect_launches), 3),
-                        "hbm_frac": round(a1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None}
+                        "hbm_frac": round(a1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None,
+                        "hbm_frac_56B": round(ISECT_BYTES_PER_RAY * u1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None}
             rr.free()
         out["modes"] = modes
+        # the reference builds WITHOUT -use_fast_math (CMakeLists.txt:26-30): FMA contraction, IEEE divide / sqrt — that is
+        # the `fma` mode; quote it beside the headline
+        out["value_fma"] = modes["fma"]["steady_value"]
+        out["value_exact"] = modes["exact"]["steady_value"]
 
         # ---- PSNR vs the 5000-spp image (always 5000, whatever --steps), outside the timed region ----
         def render_sum(n, arith=args.arith):

@@ -127,8 +127,9 @@ def lib() -> C.CDLL:
     L.pt_ctx_clear.argtypes = [C.c_void_p]
     L.pt_ctx_pixel_count.argtypes = [C.c_void_p]
     L.pt_group_create.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), _ip, C.c_int, C.POINTER(C.c_void_p)]
-    L.pt_group_create_ex.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
-    L.pt_group_transport.argtypes = [C.c_void_p]
+    if hasattr(L, "pt_group_create_ex"):  # absent only in older A/B builds loaded through PT_AMD_LIB (tools/build_rev.sh)
+        L.pt_group_create_ex.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions), _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.pt_group_transport.argtypes = [C.c_void_p]
     L.pt_group_destroy.argtypes = [C.c_void_p]
     L.pt_group_size.argtypes = [C.c_void_p]
     L.pt_group_context.argtypes = [C.c_void_p, C.c_int]

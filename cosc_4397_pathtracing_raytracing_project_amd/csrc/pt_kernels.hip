@@ -352,13 +352,8 @@ PT_DEV uint32_t path_seed(const PathTag& tag, int k, int pl, const uint32_t* iha
 // in LDS while the kernel runs (loaded by retire_begin, written back by retire_end: nobody else touches them).
 struct Retire {
   ptd::Word4* seg;  // records of segment (q, 0, r); segment (q, k, r) starts k * seg_cap records further
-  int* fill;        // LDS [K]
+  int* fill;        // LDS [K]: fill levels of the wave's segments
   int seg_cap;
-  // The iteration the wave appended to last, its segment and fill level, wave-uniform in registers: consecutive groups of
-  // a wave are neighbours in the queue's iteration-major order, so almost every append hits it and touches LDS not at all
-  // (with the fill level read from LDS per append the dependent LDS round trip cost 13 % of the bounce kernel).
-  int ck, cfill;
-  ptd::Word4* cseg;
 };
 __host__ __device__ inline int retire_wave_bytes(const SceneTables& sc) { return (sc.max_batch_iters * 4 + 15) & ~15; }
 __host__ __device__ inline int retire_lds_bytes(const SceneTables& sc) { return kWavesPerBlock * retire_wave_bytes(sc); }
@@ -368,37 +363,26 @@ PT_DEV Retire retire_begin(void* lds_base, const ptd::RetireBuf& rb, const Scene
   const int64_t s0 = ((int64_t)q * rb.R + r) * rb.kmax;
   rt.seg = rb.rec + s0 * rb.seg_cap;
   rt.seg_cap = rb.seg_cap;
-  rt.ck = -1, rt.cfill = 0, rt.cseg = rt.seg;
   for (int k = lane; k < b.K; k += 64) rt.fill[k] = rb.cnt[s0 + k];
   return rt;
 }
 PT_DEV void retire_end(const Retire& rt, const ptd::RetireBuf& rb, const BatchInfo& b, int q, int r, int lane) {
-  if (rt.ck >= 0 && lane == 0) rt.fill[rt.ck] = rt.cfill;
   const int64_t s0 = ((int64_t)q * rb.R + r) * rb.kmax;
   for (int k = lane; k < b.K; k += 64) rb.cnt[s0 + k] = rt.fill[k];
 }
-// The lanes with `dead` append (colour, tile pixel index) to the wave's segment of their iteration k: one 16-byte store per
-// lane, consecutive lanes to consecutive records.  The loop runs once per distinct iteration among the dead lanes: once,
-// rarely twice.  Wave-uniform control flow.
-PT_DEV void retire_append(Retire& rt, bool dead, int k, int pl, f3 c, int lane) {
+// The lanes with `dead` append (colour, tile pixel index) to the wave's segment of their iteration k.  The position comes
+// from ONE returning LDS atomic on the segment's fill level, issued by all dead lanes at once: lanes of the same iteration
+// get consecutive records (stores of a group's retirees stay contiguous runs), and a group whose dead lanes belong to
+// several iterations — the rule at the deep depths, where a queue's iteration-major order has been shuffled by seven
+// compactions and every remaining path retires — costs no more than one whose lanes agree.  (First version: a loop over
+// the distinct iterations with ballot / rank / a cached fill level; PMC: +135 VALU and +180 SALU per group at depth 7.)
+PT_DEV void retire_append(const Retire& rt, bool dead, int k, int pl, f3 c, int lane) {
 #ifdef PT_ABL_NO_RETIRE  // timing experiment only (wrong images)
   return;
 #endif
-  unsigned long long m = __ballot(dead);
-  while (m) {
-    const int k0 = __builtin_amdgcn_readlane(k, (int)__builtin_ctzll(m));
-    const bool mine = dead && k == k0;
-    const unsigned long long mk = __ballot(mine);
-    if (k0 != rt.ck) {  // another iteration than last time: park the cached fill level, fetch this one's
-      if (rt.ck >= 0 && lane == 0) rt.fill[rt.ck] = rt.cfill;
-      rt.ck = k0;
-      rt.cfill = __builtin_amdgcn_readfirstlane(rt.fill[k0]);
-      rt.cseg = rt.seg + (int64_t)k0 * rt.seg_cap;
-    }
-    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0));
-    if (mine) rt.cseg[rt.cfill + rank] = ptd::Word4{c.x, c.y, c.z, __int_as_float(pl)};
-    rt.cfill += __popcll(mk);
-    m &= ~mk;
+  if (dead) {
+    const int pos = atomicAdd(&rt.fill[k], 1);
+    rt.seg[(int64_t)k * rt.seg_cap + pos] = ptd::Word4{c.x, c.y, c.z, __int_as_float(pl)};
   }
 }
 // Queue q's share of an iteration (ptd::Queues): chunks q, q + Q, ... of the tile's ceil(N / 64); only the tile's last
@@ -998,7 +982,7 @@ struct Reservation {
   unsigned long long live;
   int base;
 };
-PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int k, int pl, Retire& rt, int32_t* __restrict__ counter, int lane) {
+PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int k, int pl, const Retire& rt, int32_t* __restrict__ counter, int lane) {
   // dead lanes: one 16-byte record each, appended to the wave's own segment of iteration k (retire_append) — rounds 1-2
   // scattered them over final[k * N + p], a partial DRAM line per sample
   retire_append(rt, valid && !s.alive, k, pl, s.c, lane);
@@ -1046,7 +1030,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, threadIdx.x >> 6, lane);
+  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, threadIdx.x >> 6, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t HS = hits.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
@@ -1500,7 +1484,7 @@ struct Pending {
 template <bool SMALL>
 PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
                           const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
-                          int depth, float inv_n, Retire& rt,
+                          int depth, float inv_n, const Retire& rt,
                           int32_t* __restrict__ counter, Deferred& df, int lane) {
   const unsigned long long best = cy.best[pg.par * 64 + lane];
   const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1609,7 +1593,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
+  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   // the queue's samples, iteration-major: entry j = k * my_nq + jj is chunk q + jj * Q of iteration k (same map as k_generate)
   const QueueShare sh = queue_share(b, qs, q);
   if (r == 0 && lane == 0) cnt0[(size_t)q * qs.cnt_stride] = b.K * sh.my_pixels;
@@ -1724,7 +1708,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
+  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;
@@ -1814,7 +1798,7 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
+  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_n = 1.0f / (float)b.N;

@@ -55,7 +55,21 @@ CLASSES = [('v_fma_f32', 'FMA_F32', 'v_fma_f32 %{i}, %{i}, %8, %9', 'f', ''),
     ('v_bfe_u32', 'BFE_U32', 'v_bfe_u32 %{i}, %{i}, 3, 9', 'f', ''),
     ('v_writelane_b32', 'WRITELANE', 'v_writelane_b32 %{i}, s20, 5', 'f', '"s20"'),
     ('v_subrev_f32 / v_sub_f32', 'SUB_F32', 'v_sub_f32 %{i}, %{i}, %8', 'f', ''),
-    ('v_cmp_lt_f32 -> s_and_b64 (VALU + SALU)', 'CMP_SAND', 'v_cmp_lt_f32 s[20:21], %{i}, %8\\n s_and_b64 s[22:23], s[22:23], s[20:21]', 'f', '"s20", "s21", "s22", "s23", "scc"')]
+    ('v_cmp_lt_f32 -> s_and_b64 (VALU + SALU)', 'CMP_SAND', 'v_cmp_lt_f32 s[20:21], %{i}, %8\\n s_and_b64 s[22:23], s[22:23], s[20:21]', 'f', '"s20", "s21", "s22", "s23", "scc"'),
+    ('v_and_b32', 'AND_B32', 'v_and_b32 %{i}, %{i}, %8', 'f', ''),
+    ('v_or_b32', 'OR_B32', 'v_or_b32 %{i}, %{i}, %8', 'f', ''),
+    ('v_lshlrev_b32', 'LSHL_B32', 'v_lshlrev_b32 %{i}, 3, %{i}', 'f', ''),
+    ('v_lshrrev_b32', 'LSHR_B32', 'v_lshrrev_b32 %{i}, 3, %{i}', 'f', ''),
+    ('v_sub_u32', 'SUB_U32', 'v_sub_u32 %{i}, %{i}, %8', 'f', ''),
+    ('v_min_f32', 'MIN_F32', 'v_min_f32 %{i}, %{i}, %8', 'f', ''),
+    ('v_fmac_f32', 'FMAC_F32', 'v_fmac_f32 %{i}, %8, %9', 'f', ''),
+    ('v_min_u32', 'MIN_U32', 'v_min_u32 %{i}, %{i}, %8', 'f', ''),
+    ('v_add3_u32', 'ADD3_U32', 'v_add3_u32 %{i}, %{i}, %8, %9', 'f', ''),
+    ('v_cmp_lt_f32 (to vcc)', 'CMP_VCC', 'v_cmp_lt_f32 vcc, %{i}, %8', 'f', '"vcc"'),
+    ('v_cndmask_b32 (vcc)', 'CND_VCC', 'v_cndmask_b32 %{i}, %{i}, %8, vcc', 'f', '"vcc"'),
+    ('v_ffbl_b32', 'FFBL', 'v_ffbl_b32 %{i}, %{i}', 'f', ''),
+    ('v_bfi_b32', 'BFI', 'v_bfi_b32 %{i}, %8, %{i}, %9', 'f', ''),
+]
 
 TWO_PER_LINE = {"CMP_CND", "CMP_SAND"}  # two instructions per chain line: both are counted
 

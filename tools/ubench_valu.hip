@@ -20,8 +20,8 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum Cls { FMA_F32, MUL_F32, ADD_F32, MAX_F32, CNDMASK, CMP_F32, CMP_CND, RCP_F32, RSQ_F32, SQRT_F32, SIN_F32, COS_F32, MUL_LO_U32, MUL_HI_U32, MAD_U64_U32, MUL_U32_U24, MAD_U32_U24, ADD_U32, LSHL_ADD, XOR_B32, AND_OR, CVT_F32_U32, CVT_U32_F32, FMA_F64, MUL_F64, ADD_F64, DIV_FIXUP, DIV_SCALE, DIV_FMAS, MOV_B32, MBCNT, READLANE, READFIRST, DPP_MOV, BPERMUTE, DS_READ_B32, DS_READ_B128_BCAST, DS_WRITE_B32, SALU, PK_FMA_F32, PK_MUL_F32, PK_ADD_F32, MAX3_F32, MIN3_F32, LSHL_ADD_U64, ALIGNBIT, BFE_U32, WRITELANE, SUB_F32, CMP_SAND, NUM_CLS };
-static const char* kNames[NUM_CLS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_max_f32", "v_cndmask_b32 (mask in SGPRs)", "v_cmp_lt_f32 (to SGPR pair)", "v_cmp_lt_f32 + v_cndmask_b32 (vcc)", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_lshl_add_u32", "v_xor_b32", "v_and_or_b32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_div_fixup_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_mov_b32", "v_mbcnt_lo_u32_b32", "v_readlane_b32", "v_readfirstlane_b32", "v_mov_b32 dpp row_shr:1", "ds_bpermute_b32", "ds_read_b32 (lane-consecutive)", "ds_read_b128 (uniform address)", "ds_write_b32 (lane-consecutive)", "s_and_b64 (SALU beside nothing)", "v_pk_fma_f32 (2 FMAs per lane)", "v_pk_mul_f32", "v_pk_add_f32", "v_max3_f32", "v_min3_f32", "v_lshl_add_u64", "v_alignbit_b32", "v_bfe_u32", "v_writelane_b32", "v_subrev_f32 / v_sub_f32", "v_cmp_lt_f32 -> s_and_b64 (VALU + SALU)"};
+enum Cls { FMA_F32, MUL_F32, ADD_F32, MAX_F32, CNDMASK, CMP_F32, CMP_CND, RCP_F32, RSQ_F32, SQRT_F32, SIN_F32, COS_F32, MUL_LO_U32, MUL_HI_U32, MAD_U64_U32, MUL_U32_U24, MAD_U32_U24, ADD_U32, LSHL_ADD, XOR_B32, AND_OR, CVT_F32_U32, CVT_U32_F32, FMA_F64, MUL_F64, ADD_F64, DIV_FIXUP, DIV_SCALE, DIV_FMAS, MOV_B32, MBCNT, READLANE, READFIRST, DPP_MOV, BPERMUTE, DS_READ_B32, DS_READ_B128_BCAST, DS_WRITE_B32, SALU, PK_FMA_F32, PK_MUL_F32, PK_ADD_F32, MAX3_F32, MIN3_F32, LSHL_ADD_U64, ALIGNBIT, BFE_U32, WRITELANE, SUB_F32, CMP_SAND, AND_B32, OR_B32, LSHL_B32, LSHR_B32, SUB_U32, MIN_F32, FMAC_F32, MIN_U32, ADD3_U32, CMP_VCC, CND_VCC, FFBL, BFI, NUM_CLS };
+static const char* kNames[NUM_CLS] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_max_f32", "v_cndmask_b32 (mask in SGPRs)", "v_cmp_lt_f32 (to SGPR pair)", "v_cmp_lt_f32 + v_cndmask_b32 (vcc)", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mul_u32_u24", "v_mad_u32_u24", "v_add_u32", "v_lshl_add_u32", "v_xor_b32", "v_and_or_b32", "v_cvt_f32_u32", "v_cvt_u32_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_div_fixup_f32", "v_div_scale_f32", "v_div_fmas_f32", "v_mov_b32", "v_mbcnt_lo_u32_b32", "v_readlane_b32", "v_readfirstlane_b32", "v_mov_b32 dpp row_shr:1", "ds_bpermute_b32", "ds_read_b32 (lane-consecutive)", "ds_read_b128 (uniform address)", "ds_write_b32 (lane-consecutive)", "s_and_b64 (SALU beside nothing)", "v_pk_fma_f32 (2 FMAs per lane)", "v_pk_mul_f32", "v_pk_add_f32", "v_max3_f32", "v_min3_f32", "v_lshl_add_u64", "v_alignbit_b32", "v_bfe_u32", "v_writelane_b32", "v_subrev_f32 / v_sub_f32", "v_cmp_lt_f32 -> s_and_b64 (VALU + SALU)", "v_and_b32", "v_or_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_sub_u32", "v_min_f32", "v_fmac_f32", "v_min_u32", "v_add3_u32", "v_cmp_lt_f32 (to vcc)", "v_cndmask_b32 (vcc)", "v_ffbl_b32", "v_bfi_b32"};
 
 constexpr int kPerTrip = 64;  // 4 asm statements x 16 instructions (CMP_CND: 2 instructions per line, counted below)
 
@@ -83,6 +83,19 @@ __device__ __forceinline__ void body(float (&x)[8], double (&dd)[8], unsigned lo
     if constexpr (C == WRITELANE) asm volatile("v_writelane_b32 %0, s20, 5\n v_writelane_b32 %1, s20, 5\n v_writelane_b32 %2, s20, 5\n v_writelane_b32 %3, s20, 5\n v_writelane_b32 %4, s20, 5\n v_writelane_b32 %5, s20, 5\n v_writelane_b32 %6, s20, 5\n v_writelane_b32 %7, s20, 5\n v_writelane_b32 %0, s20, 5\n v_writelane_b32 %1, s20, 5\n v_writelane_b32 %2, s20, 5\n v_writelane_b32 %3, s20, 5\n v_writelane_b32 %4, s20, 5\n v_writelane_b32 %5, s20, 5\n v_writelane_b32 %6, s20, 5\n v_writelane_b32 %7, s20, 5" : OPS_F : "v"(a), "v"(b) : "s20");
     if constexpr (C == SUB_F32) asm volatile("v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8\n v_sub_f32 %0, %0, %8\n v_sub_f32 %1, %1, %8\n v_sub_f32 %2, %2, %8\n v_sub_f32 %3, %3, %8\n v_sub_f32 %4, %4, %8\n v_sub_f32 %5, %5, %8\n v_sub_f32 %6, %6, %8\n v_sub_f32 %7, %7, %8" : OPS_F : "v"(a), "v"(b));
     if constexpr (C == CMP_SAND) asm volatile("v_cmp_lt_f32 s[20:21], %0, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %1, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %2, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %3, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %4, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %5, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %6, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %7, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %0, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %1, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %2, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %3, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %4, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %5, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %6, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]\n v_cmp_lt_f32 s[20:21], %7, %8\n s_and_b64 s[22:23], s[22:23], s[20:21]" : OPS_F : "v"(a), "v"(b) : "s20", "s21", "s22", "s23", "scc");
+    if constexpr (C == AND_B32) asm volatile("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == OR_B32) asm volatile("v_or_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_or_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n v_or_b32 %4, %4, %8\n v_or_b32 %5, %5, %8\n v_or_b32 %6, %6, %8\n v_or_b32 %7, %7, %8\n v_or_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_or_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n v_or_b32 %4, %4, %8\n v_or_b32 %5, %5, %8\n v_or_b32 %6, %6, %8\n v_or_b32 %7, %7, %8" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == LSHL_B32) asm volatile("v_lshlrev_b32 %0, 3, %0\n v_lshlrev_b32 %1, 3, %1\n v_lshlrev_b32 %2, 3, %2\n v_lshlrev_b32 %3, 3, %3\n v_lshlrev_b32 %4, 3, %4\n v_lshlrev_b32 %5, 3, %5\n v_lshlrev_b32 %6, 3, %6\n v_lshlrev_b32 %7, 3, %7\n v_lshlrev_b32 %0, 3, %0\n v_lshlrev_b32 %1, 3, %1\n v_lshlrev_b32 %2, 3, %2\n v_lshlrev_b32 %3, 3, %3\n v_lshlrev_b32 %4, 3, %4\n v_lshlrev_b32 %5, 3, %5\n v_lshlrev_b32 %6, 3, %6\n v_lshlrev_b32 %7, 3, %7" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == LSHR_B32) asm volatile("v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3\n v_lshrrev_b32 %4, 3, %4\n v_lshrrev_b32 %5, 3, %5\n v_lshrrev_b32 %6, 3, %6\n v_lshrrev_b32 %7, 3, %7\n v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3\n v_lshrrev_b32 %4, 3, %4\n v_lshrrev_b32 %5, 3, %5\n v_lshrrev_b32 %6, 3, %6\n v_lshrrev_b32 %7, 3, %7" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == SUB_U32) asm volatile("v_sub_u32 %0, %0, %8\n v_sub_u32 %1, %1, %8\n v_sub_u32 %2, %2, %8\n v_sub_u32 %3, %3, %8\n v_sub_u32 %4, %4, %8\n v_sub_u32 %5, %5, %8\n v_sub_u32 %6, %6, %8\n v_sub_u32 %7, %7, %8\n v_sub_u32 %0, %0, %8\n v_sub_u32 %1, %1, %8\n v_sub_u32 %2, %2, %8\n v_sub_u32 %3, %3, %8\n v_sub_u32 %4, %4, %8\n v_sub_u32 %5, %5, %8\n v_sub_u32 %6, %6, %8\n v_sub_u32 %7, %7, %8" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == MIN_F32) asm volatile("v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8\n v_min_f32 %0, %0, %8\n v_min_f32 %1, %1, %8\n v_min_f32 %2, %2, %8\n v_min_f32 %3, %3, %8\n v_min_f32 %4, %4, %8\n v_min_f32 %5, %5, %8\n v_min_f32 %6, %6, %8\n v_min_f32 %7, %7, %8" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == FMAC_F32) asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9\n v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == MIN_U32) asm volatile("v_min_u32 %0, %0, %8\n v_min_u32 %1, %1, %8\n v_min_u32 %2, %2, %8\n v_min_u32 %3, %3, %8\n v_min_u32 %4, %4, %8\n v_min_u32 %5, %5, %8\n v_min_u32 %6, %6, %8\n v_min_u32 %7, %7, %8\n v_min_u32 %0, %0, %8\n v_min_u32 %1, %1, %8\n v_min_u32 %2, %2, %8\n v_min_u32 %3, %3, %8\n v_min_u32 %4, %4, %8\n v_min_u32 %5, %5, %8\n v_min_u32 %6, %6, %8\n v_min_u32 %7, %7, %8" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == ADD3_U32) asm volatile("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9\n v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == CMP_VCC) asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8\n v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8" : OPS_F : "v"(a), "v"(b) : "vcc");
+    if constexpr (C == CND_VCC) asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : OPS_F : "v"(a), "v"(b) : "vcc");
+    if constexpr (C == FFBL) asm volatile("v_ffbl_b32 %0, %0\n v_ffbl_b32 %1, %1\n v_ffbl_b32 %2, %2\n v_ffbl_b32 %3, %3\n v_ffbl_b32 %4, %4\n v_ffbl_b32 %5, %5\n v_ffbl_b32 %6, %6\n v_ffbl_b32 %7, %7\n v_ffbl_b32 %0, %0\n v_ffbl_b32 %1, %1\n v_ffbl_b32 %2, %2\n v_ffbl_b32 %3, %3\n v_ffbl_b32 %4, %4\n v_ffbl_b32 %5, %5\n v_ffbl_b32 %6, %6\n v_ffbl_b32 %7, %7" : OPS_F : "v"(a), "v"(b));
+    if constexpr (C == BFI) asm volatile("v_bfi_b32 %0, %8, %0, %9\n v_bfi_b32 %1, %8, %1, %9\n v_bfi_b32 %2, %8, %2, %9\n v_bfi_b32 %3, %8, %3, %9\n v_bfi_b32 %4, %8, %4, %9\n v_bfi_b32 %5, %8, %5, %9\n v_bfi_b32 %6, %8, %6, %9\n v_bfi_b32 %7, %8, %7, %9\n v_bfi_b32 %0, %8, %0, %9\n v_bfi_b32 %1, %8, %1, %9\n v_bfi_b32 %2, %8, %2, %9\n v_bfi_b32 %3, %8, %3, %9\n v_bfi_b32 %4, %8, %4, %9\n v_bfi_b32 %5, %8, %5, %9\n v_bfi_b32 %6, %8, %6, %9\n v_bfi_b32 %7, %8, %7, %9" : OPS_F : "v"(a), "v"(b));
   }
 }
 
@@ -214,5 +227,18 @@ int main() {
   run<WRITELANE>(d_out, d_st, num_cus);
   run<SUB_F32>(d_out, d_st, num_cus);
   run<CMP_SAND>(d_out, d_st, num_cus);
+  run<AND_B32>(d_out, d_st, num_cus);
+  run<OR_B32>(d_out, d_st, num_cus);
+  run<LSHL_B32>(d_out, d_st, num_cus);
+  run<LSHR_B32>(d_out, d_st, num_cus);
+  run<SUB_U32>(d_out, d_st, num_cus);
+  run<MIN_F32>(d_out, d_st, num_cus);
+  run<FMAC_F32>(d_out, d_st, num_cus);
+  run<MIN_U32>(d_out, d_st, num_cus);
+  run<ADD3_U32>(d_out, d_st, num_cus);
+  run<CMP_VCC>(d_out, d_st, num_cus);
+  run<CND_VCC>(d_out, d_st, num_cus);
+  run<FFBL>(d_out, d_st, num_cus);
+  run<BFI>(d_out, d_st, num_cus);
   return 0;
 }
