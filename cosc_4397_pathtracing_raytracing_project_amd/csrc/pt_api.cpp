@@ -75,6 +75,7 @@ struct PtContext {
   int depth = 0;
   // tile / batch geometry
   int N = 0, pixel_begin = 0, K = 1;
+  int slot_shift = 0;  // BatchInfo::slot_shift
   int stripe = 0, stripe_stride = 0;
   int num_cus = 0, grid = 0;  // grid: widest persistent grid (stats / test stages)
   int grid_gen = 0, grid_isect = 0, grid_shade = 0;
@@ -468,6 +469,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   b.N = g.N;
   b.pixel_begin = g.pixel_begin;
   b.trace_depth = g.depth;
+  b.slot_shift = g.slot_shift;
   b.aa_jitter = g.aa_jitter ? 1 : 0;
   b.debug = kAblateBuild ? g.debug_flags : 0;
   b.stripe = g.stripe;
@@ -668,7 +670,11 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
                                         // launch boundaries drop below 1 % of a batch (measured K=6 → 48: +8 %)
     K = (int)std::max<int64_t>(1, std::min<int64_t>(256, (target + g.N - 1) / g.N));
   }
-  while ((int64_t)K * g.N > (1ll << 30) && K > 1) --K;
+  // sample ids are k << slot_shift | tile pixel in 31 bits (BatchInfo::slot_shift)
+  g.slot_shift = 1;
+  while ((1ll << g.slot_shift) < g.N) ++g.slot_shift;
+  if (g.slot_shift > 30) return fail("pt_init: tiles of more than 2^30 pixels are not supported");
+  while (K > 1 && K > (1 << (31 - g.slot_shift))) --K;
 
   // Compaction queues: every launch needs (waves % Q) == 0, so Q divides 4 * CUs.  A queue owns every Q-th 64-pixel
   // chunk of the tile in every iteration (pt_device.h); k_collect wants at most 128 chunks per queue (one LDS tile per
@@ -1118,6 +1124,7 @@ int pt_stage_generate(int pix_begin, int n, float* origin, float* dir) {
   const ptd::PathBuf pb = sp.pb;
   ptk::BatchInfo b{};
   b.iter_first = 1, b.K = 1, b.N = n, b.pixel_begin = pix_begin, b.trace_depth = g.depth;
+  b.slot_shift = 30;
   b.aa_jitter = g.aa_jitter ? 1 : 0;
   g.k->generate(g.stream, g.grid, g.dcam, b, qs, pb, cnt);
   HIP_OK(hipStreamSynchronize(g.stream));

@@ -66,6 +66,7 @@ struct BatchInfo {
   int32_t stripe, gap;
   float inv_stripe;
   int32_t trace_depth;
+  int32_t slot_shift;  // sample id of a path = k << slot_shift | tile pixel; 2^slot_shift >= N, k < 2^(31 - slot_shift)
   int32_t aa_jitter;  // 1: stochastic anti-aliasing of the camera rays (extension, PtOptions.aa_jitter)
   int32_t debug;  // profiling ablations (wrong results; honoured only by -DPT_ABLATE builds): 4 = skip primitive tests,
                   // 8 = skip shade_bounce

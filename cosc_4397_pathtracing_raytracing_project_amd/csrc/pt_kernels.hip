@@ -334,10 +334,12 @@ PT_DEV void path_store(const ptd::PathBuf& b, int64_t at, f3 o, f3 d, f3 c, cons
   b.r[b.stride + at] = ptd::Word4{d.y, d.z, c.x, c.y};
   plane2_store(b, at, c.z, tag);
 }
-// Iteration (inside the batch) and tile pixel of a path: carried (kTagged) or from the sample id k * N + pl.
-PT_DEV void sample_of(const PathTag& tag, const BatchInfo& b, float inv_n, int& k, int& pl) {
-  divmod(tag.slot, b.N, inv_n, k, pl);
-  if constexpr (kTagged) k = tag.k;
+// Iteration (inside the batch) and tile pixel of a path from its sample id k << slot_shift | pl (BatchInfo::slot_shift: a
+// shift and a mask instead of the division by N that the id k * N + pl of rounds 1-2 needed at every depth).
+PT_DEV int make_slot(const BatchInfo& b, int k, int pl) { return (k << b.slot_shift) | pl; }
+PT_DEV void sample_of(const PathTag& tag, const BatchInfo& b, int& k, int& pl) {
+  k = (int)((uint32_t)tag.slot >> b.slot_shift);
+  pl = tag.slot & ((1 << b.slot_shift) - 1);
 }
 // makeSeededRandomEngine's seed (pathtrace.cu:205) of a path at `depth`: utilhash((1 << 31) | depth << 22 | iteration) ^
 // utilhash(global pixel index).  The first factor comes from the per-block table (iter_hash_of); the second rides along
@@ -376,14 +378,12 @@ PT_DEV void retire_end(const Retire& rt, const ptd::RetireBuf& rb, const BatchIn
 // several iterations — the rule at the deep depths, where a queue's iteration-major order has been shuffled by seven
 // compactions and every remaining path retires — costs no more than one whose lanes agree.  (First version: a loop over
 // the distinct iterations with ballot / rank / a cached fill level; PMC: +135 VALU and +180 SALU per group at depth 7.)
-PT_DEV void retire_append(const Retire& rt, bool dead, int k, int pl, f3 c, int lane) {
+PT_DEV int retire_reserve(const Retire& rt, bool dead, int k) { return dead ? atomicAdd(&rt.fill[k], 1) : 0; }
+PT_DEV void retire_store(const Retire& rt, bool dead, int k, int pos, int pl, f3 c) {
 #ifdef PT_ABL_NO_RETIRE  // timing experiment only (wrong images)
   return;
 #endif
-  if (dead) {
-    const int pos = atomicAdd(&rt.fill[k], 1);
-    rt.seg[(int64_t)k * rt.seg_cap + pos] = ptd::Word4{c.x, c.y, c.z, __int_as_float(pl)};
-  }
+  if (dead) rt.seg[(int64_t)k * rt.seg_cap + pos] = ptd::Word4{c.x, c.y, c.z, __int_as_float(pl)};
 }
 // Queue q's share of an iteration (ptd::Queues): chunks q, q + Q, ... of the tile's ceil(N / 64); only the tile's last
 // chunk can be partial, and it is the last chunk of the queue that owns it.
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(ptd::Camera cam, BatchInfo 
       if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
       const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
       const int64_t at = (int64_t)q * qs.cap + (int64_t)k * sh.my_pixels + jj * 64 + lane;  // dense: a partial chunk is the queue's last
-      path_store(out, at, mk(cam.pos[0], cam.pos[1], cam.pos[2]), d, mk(1.0f, 1.0f, 1.0f), PathTag{k * b.N + pl, utilhash((uint32_t)p), k});
+      path_store(out, at, mk(cam.pos[0], cam.pos[1], cam.pos[2]), d, mk(1.0f, 1.0f, 1.0f), PathTag{make_slot(b, k, pl), utilhash((uint32_t)p), k});
     }
   }
 }
@@ -981,12 +981,18 @@ PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
 struct Reservation {
   unsigned long long live;
   int base;
+  int rpos;  // dead lanes: the lane's record position in its retirement segment
 };
+// DEFER_RETIRE: the retirement records are stored by flush_deferred one loop iteration later, together with the survivors
+// (fused kernels: every store of an iteration is then issued right after the iteration's one vector-memory wait and has a
+// whole iteration to be acknowledged before the next — vmcnt counts stores too).
+template <bool DEFER_RETIRE = false>
 PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int k, int pl, const Retire& rt, int32_t* __restrict__ counter, int lane) {
-  // dead lanes: one 16-byte record each, appended to the wave's own segment of iteration k (retire_append) — rounds 1-2
-  // scattered them over final[k * N + p], a partial DRAM line per sample
-  retire_append(rt, valid && !s.alive, k, pl, s.c, lane);
+  // dead lanes: one 16-byte record each, appended to the wave's own segment of iteration k (retire_reserve / retire_store)
+  // — rounds 1-2 scattered them over final[k * N + p], a partial DRAM line per sample
   Reservation r;
+  r.rpos = retire_reserve(rt, valid && !s.alive, k);
+  if (!DEFER_RETIRE) retire_store(rt, valid && !s.alive, k, r.rpos, pl, s.c);
   r.live = __ballot(valid && s.alive);
   r.base = 0;
   if (r.live && lane == 0) r.base = atomicAdd(counter, __popcll(r.live));
@@ -1007,11 +1013,16 @@ struct Deferred {
   Reservation res;
   ShadeIO s;
   PathTag tag;
-  bool alive;
-  bool any;  // wave-uniform: survivors pending
+  bool alive, dead;
+  bool any;  // wave-uniform: a shaded group's stores are pending
 };
-PT_DEV void flush_deferred(Deferred& df, int64_t qbase, ptd::PathBuf out) {
-  if (df.any) emit_survivors(df.res, df.alive, df.s, df.tag, qbase, out);
+PT_DEV void flush_deferred(Deferred& df, int64_t qbase, ptd::PathBuf out, const Retire& rt, const BatchInfo& b) {
+  if (df.any) {
+    emit_survivors(df.res, df.alive, df.s, df.tag, qbase, out);
+    int k, pl;
+    sample_of(df.tag, b, k, pl);
+    retire_store(rt, df.dead, k, df.res.rpos, pl, df.s.c);
+  }
   df.any = false;
 }
 
@@ -1034,7 +1045,6 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t HS = hits.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
-  const float inv_n = 1.0f / (float)b.N;
   // inputs of one path; the next group's are loaded (branch-free, index clamped into the queue's own
   // region) while the current group is shaded
   struct In {
@@ -1068,7 +1078,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     Bounce bo;
     bo.kind = 0;
     int k, pl;
-    sample_of(cur.tag, b, inv_n, k, pl);
+    sample_of(cur.tag, b, k, pl);
     if (valid) bo = shade_decide(mats, b.trace_depth, depth, path_seed(cur.tag, k, pl, ihash, sc, b, depth), cur.ht, cur.hmat, s);
     const Reservation res = retire_and_reserve(valid, s, k, pl, rt, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
@@ -1484,7 +1494,7 @@ struct Pending {
 template <bool SMALL>
 PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
                           const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
-                          int depth, float inv_n, const Retire& rt,
+                          int depth, const Retire& rt,
                           int32_t* __restrict__ counter, Deferred& df, int lane) {
   const unsigned long long best = cy.best[pg.par * 64 + lane];
   const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1497,7 +1507,7 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
   bo.kind = 0;
   f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
   int k, pl;
-  sample_of(pg.tag, b, inv_n, k, pl);
+  sample_of(pg.tag, b, k, pl);
   if (pg.valid) {
     float ht = -1.0f;
     int hmat = 0;
@@ -1510,13 +1520,14 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
     }
     bo = shade_decide(mats, b.trace_depth, depth, path_seed(pg.tag, k, pl, ihash, sc, b, depth), ht, hmat, s);
   }
-  df.res = retire_and_reserve(pg.valid, s, k, pl, rt, counter, lane);
+  df.res = retire_and_reserve<true>(pg.valid, s, k, pl, rt, counter, lane);
   const bool alive = pg.valid && s.alive;
   if (alive && !(kAblate && (b.debug & 8))) shade_bounce(bo, hn, hp, s);
   df.s = s;
   df.tag = pg.tag;
   df.alive = alive;
-  df.any = df.res.live != 0;
+  df.dead = pg.valid && !s.alive;
+  df.any = true;
 }
 
 // ── depth 0 fused: generateRayFromCamera + computeIntersections + shadeAndExtendRays ────────
@@ -1609,7 +1620,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     const int pl_raw = (q + jj * qs.Q) * 64 + lane;
     const bool valid = pl_raw < b.N;
     const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
-    const int slot = k * b.N + pl;
+    const int slot = make_slot(b, k, pl);
     const int p = global_pixel(b, pl);  // global pixel index
     const uint32_t phash = utilhash((uint32_t)p);  // rides along with the path from here on (kTagged)
     float jx = 0.f, jy = 0.f;
@@ -1631,7 +1642,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     } else {
       w.best[lane] = kNoHit;
     }
-    flush_deferred(df, qbase, out);  // the previous chunk's survivors (see Deferred)
+    flush_deferred(df, qbase, out, rt, b);  // the previous chunk's survivors (see Deferred)
     const unsigned long long best = w.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
     ShadeIO s;
@@ -1655,15 +1666,16 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
     }
-    df.res = retire_and_reserve(valid, s, k, pl, rt, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    df.res = retire_and_reserve<true>(valid, s, k, pl, rt, &cnt_out[(size_t)q * qs.cnt_stride], lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
     df.s = s;
     df.tag = PathTag{slot, phash, k};
     df.alive = alive;
-    df.any = df.res.live != 0;
+    df.dead = valid && !s.alive;
+    df.any = true;
   }
-  flush_deferred(df, qbase, out);
+  flush_deferred(df, qbase, out, rt, b);
   retire_end(rt, ret, b, q, r, lane);
 }
 
@@ -1711,7 +1723,6 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t qbase = (int64_t)q * qs.cap;
-  const float inv_n = 1.0f / (float)b.N;
   const int last = qs.cap - 64 + lane;  // branch-free loads, clamped into the queue's own region
   auto load = [&](int i) { return path_load(in, qbase + min(i, last)); };
   PathRec nx = load(r * 64 + lane);
@@ -1740,8 +1751,8 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
     // previous group's reservation) is a whole candidate search old, so that this is the iteration's only vector-memory
     // wait; the stores and the atomic below then have until the same point of the next iteration.
     PT_TOUCH_PREFETCH();
-    flush_deferred(df, qbase, out);  // survivors of the group shaded one iteration ago
-    if (pg.any) shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, rt, counter, df, lane);
+    flush_deferred(df, qbase, out, rt, b);  // survivors of the group shaded one iteration ago
+    if (pg.any) shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, rt, counter, df, lane);
     pg.d = cur.d;
     pg.c = cur.c;
     pg.tag = cur.tag;
@@ -1750,11 +1761,11 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
     pg.mark = cy.appended;
     pg.any = true;
   }
-  flush_deferred(df, qbase, out);
+  flush_deferred(df, qbase, out, rt, b);
   if (pg.any) {
     carry_drain_to(cy, pg.mark, lane, nodes, geoms);
-    shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, inv_n, rt, counter, df, lane);
-    flush_deferred(df, qbase, out);
+    shade_pending(sc, cy, pg, mats, ihash, nodes, geoms, b, depth, rt, counter, df, lane);
+    flush_deferred(df, qbase, out, rt, b);
   }
   retire_end(rt, ret, b, q, r, lane);
 }
@@ -1801,7 +1812,6 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t qbase = (int64_t)q * qs.cap;
-  const float inv_n = 1.0f / (float)b.N;
   const int last = qs.cap - 64 + lane;
   int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
   for (int j = r; j * 64 < n_q; j += wq) {
@@ -1823,7 +1833,7 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
     path_load_tail(in, at, s.d, s.c, tag);
     s.alive = false;
     int k, pl;
-    sample_of(tag, b, inv_n, k, pl);
+    sample_of(tag, b, k, pl);
     const unsigned long long best = cy.best[lane];
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
     Bounce bo;
