@@ -1113,6 +1113,7 @@ struct Carry {
   float* ray;                // [2][6][64]  origin xyz, direction xyz of each lane's ray, by group parity
   int* slot;                 // [64]        scratch of the work-stealing step (carry_search); not SMALL only
   uint32_t* gix;             // [kRing]     LEAN chunks (grid walk) only: geom index | primitive type << 30 of each ring entry
+  const float* qo_tab;       // QO chunks (primary rays) only: the camera position in every geom's object space, [geom][3]
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
   int debug;                 // BatchInfo::debug
@@ -1132,13 +1133,15 @@ PT_DEV Carry<SMALL, NPAR> carry_init(char* base) {
   c.head = c.count = c.appended = c.processed = 0;
   c.debug = 0;
   c.gix = nullptr;
+  c.qo_tab = nullptr;
   return c;
 }
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
 // LEAN (the grid walk): the geom index and primitive type come with the ring entry (Carry::gix) instead of through
 // nodes[leaf] and the geom record, and the world-space normal is computed for the winner only (finish_normal): 6
 // 16-byte reads per candidate instead of 9 (cube) or 11 (sphere) — the L1's access rate is what bounds those kernels.
-template <bool SMALL, int NPAR, bool EX = false, bool LEAN = false>
+// QO (the primary kernel's ring): every ray starts at the camera, whose object-space image per geom comes from Carry::qo_tab.
+template <bool SMALL, int NPAR, bool EX = false, bool LEAN = false, bool QO = false>
 PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
@@ -1151,12 +1154,14 @@ PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node*
   const f3 ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
   const f3 rd = mk(ray[3 * 64], ray[4 * 64], ray[5 * 64]);
   const uint32_t gw = LEAN ? c.gix[idx] : 0u;
-  const ptd::Geom* G = geoms + (valid ? (LEAN ? (int)(gw & 0x3fffffffu) : nodes[leaf].geom) : 0);
+  const int gi = valid ? (LEAN ? (int)(gw & 0x3fffffffu) : nodes[leaf].geom) : 0;
+  const ptd::Geom* G = geoms + gi;
   f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
   float t = -1.0f;
   // cube / sphere decided per lane; shared pre and post parts
   if (!(kAblate && (c.debug & 4))) {
     if (LEAN) t = Ar<EX>::template geom_test<-1, false, true>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f), valid ? (int)(gw >> 30) : 0);
+    else if (QO) t = Ar<EX>::template geom_test<-1, true>(G, ro, rd, pt, nrm, mk(c.qo_tab[3 * gi], c.qo_tab[3 * gi + 1], c.qo_tab[3 * gi + 2]));
     else t = Ar<EX>::template geom_test<-1, false>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f));
   }
   const uint32_t tb = __float_as_uint(t);
@@ -1195,11 +1200,14 @@ PT_DEV void carry_append(Carry<SMALL, NPAR>& c, bool pass, uint32_t leaf, int pa
 // Candidate search of one group (phase 1 of trace_group) feeding the ring.
 // SUB: the scene has subtrees below the top list.  The LDS-table kernels are only used for scenes whose leaves all
 // fit the top list (auto_lds_table_limit), so their instantiation drops the subtree scan.
-template <bool SUB, int NPAR>
+// CAM (primary rays, !SUB only): `top` holds the boxes relative to the camera position (slab_rel), EX selects the
+// reference's exact arithmetic, and the chunks take the object-space origin from Carry::qo_tab.
+template <bool SUB, int NPAR, bool CAM = false, bool EX = false>
 PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
                          unsigned long long top_xor) {
-  const RayInv ri = ray_inv(d, o);
+  static_assert(!(CAM && SUB), "camera-relative search: LDS-table scenes only");
+  const RayInv ri = Ar<EX>::ray_inv(d, o);
   {
     float* ray = c.ray + par * 6 * 64 + lane;  // this group's rays, read back by the primitive-test chunks
     ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
@@ -1211,16 +1219,19 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
     // round j every lane that still has candidates files one, so the ballot / rank / ring arithmetic runs once per round
     // (max candidates of a lane, ~3) instead of once per entry (7 for cornell.txt).  The order of the ring entries changes,
     // the set does not, and the closest-hit key is order-independent.
+    auto box = [&](const float4& A, const float4& B) {
+      return CAM ? Ar<EX>::slab_rel(ri, A.x, A.y, A.z, A.w, B.x, B.y) : Ar<EX>::slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y);
+    };
     uint32_t mask = 0;
     float4 A0 = top[0], B0 = top[1];
     int e = 0;
     for (; e + 1 < ntop; e += 2) {
       const float4 A1 = top[2 * e + 2], B1 = top[2 * e + 3];
-      mask |= slab(o, ri, A0.x, A0.y, A0.z, A0.w, B0.x, B0.y) ? (1u << e) : 0u;
+      mask |= box(A0, B0) ? (1u << e) : 0u;
       if (e + 2 < ntop) A0 = top[2 * e + 4], B0 = top[2 * e + 5];
-      mask |= slab(o, ri, A1.x, A1.y, A1.z, A1.w, B1.x, B1.y) ? (2u << e) : 0u;
+      mask |= box(A1, B1) ? (2u << e) : 0u;
     }
-    if (e < ntop) mask |= slab(o, ri, A0.x, A0.y, A0.z, A0.w, B0.x, B0.y) ? (1u << e) : 0u;
+    if (e < ntop) mask |= box(A0, B0) ? (1u << e) : 0u;
     mask = valid ? mask : 0u;
     const uint32_t tag = ((uint32_t)par << 6) | (uint32_t)lane;
     while (true) {
@@ -1236,7 +1247,7 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
       const int cnt = __popcll(m);
       c.count += cnt;
       c.appended += cnt;
-      if (c.count >= 64) carry_chunk(c, 64, lane, nodes, geoms);
+      if (c.count >= 64) carry_chunk<!SUB, NPAR, EX, false, CAM>(c, 64, lane, nodes, geoms);
     }
     return;
   }
@@ -1280,10 +1291,10 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
 }
 // Make sure everything appended up to `mark` has been tested (only runs a partial chunk when the ring
 // did not fill up since).
-template <bool SMALL, int NPAR>
+template <bool SMALL, int NPAR, bool EX = false, bool QO = false>
 PT_DEV void carry_drain_to(Carry<SMALL, NPAR>& c, int mark, int lane, const ptd::Node* __restrict__ nodes,
                            const ptd::Geom* __restrict__ geoms) {
-  while (c.processed - mark < 0) carry_chunk(c, min(64, c.count), lane, nodes, geoms);
+  while (c.processed - mark < 0) carry_chunk<SMALL, NPAR, EX, false, QO>(c, min(64, c.count), lane, nodes, geoms);
 }
 
 // ── uniform grid walk (SceneTables::grid_*; large scenes, when faster than the BVH scan) ───────────────────────────────
@@ -1539,6 +1550,16 @@ PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const P
 // where every sample is alive.  Also writes the per-queue sample counts of depth 0 (statistics).
 // GRID: large scenes with a uniform grid over the leaf boxes (SceneTables::use_grid): the primary rays walk it like the
 // bounce rays do (grid_search) instead of testing the top list and scanning subtrees; exact arithmetic as in every depth-0 path.
+// RING (the LDS-table scenes, e.g. cornell.txt): the candidates go through the bounce kernel's ring with carry-over
+// (carry_search / carry_chunk), so that primitive tests only ever run as full 64-entry chunks — a group of primary rays
+// files ~85 candidates, which the per-group form (trace_group) ran as one full chunk plus one a third full — and the
+// appends run lane-major (two-phase search).  A group is shaded one loop iteration after its search, like in k_bounce.
+// Unlike the ring form tried in round 2 it keeps the camera-relative boxes and the per-geom object-space camera position.
+#ifndef PT_PRIMARY_RING
+#define PT_PRIMARY_RING 1
+#endif
+template <bool TABLES_IN_LDS, bool GRID>
+constexpr bool primary_ring() { return PT_PRIMARY_RING != 0 && TABLES_IN_LDS && !GRID; }
 template <bool TABLES_IN_LDS, bool GRID = false>
 __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables sc, ptd::Camera cam, BatchInfo b, ptd::Queues qs,
                                                     int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
@@ -1563,7 +1584,8 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
     tbl += nb_nodes + nb_geoms;
   }
-  constexpr int kWaveBytes = GRID ? grid_wave_bytes<kD0>() : kWaveLds;
+  constexpr bool RING = primary_ring<TABLES_IN_LDS, GRID>();
+  constexpr int kWaveBytes = GRID ? grid_wave_bytes<kD0>() : (RING ? carry_bytes<true, 2>() : kWaveLds);
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);  // after the per-wave blocks
   iter_hash_fill(ihash, sc, b, 0);
   // camera-relative copies for the primary rays: top-list boxes minus the camera position and (tables in LDS only)
@@ -1614,36 +1636,9 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
   Deferred df;
   df.any = false;
-  for (int j = r; j < entries; j += wq) {
-    int k, jj;
-    divmod(j, sh.my_nq, sh.inv_my_nq, k, jj);
-    const int pl_raw = (q + jj * qs.Q) * 64 + lane;
-    const bool valid = pl_raw < b.N;
-    const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
-    const int slot = make_slot(b, k, pl);
-    const int p = global_pixel(b, pl);  // global pixel index
-    const uint32_t phash = utilhash((uint32_t)p);  // rides along with the path from here on (kTagged)
-    float jx = 0.f, jy = 0.f;
-    if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
-    const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
-    // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
-    // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
-    // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
-    const bool near_scene = __ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
-                                                   sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if (GRID) {
-      w.best[lane] = kNoHit;
-      if (near_scene) {
-        grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
-        while (cy.count > 0) carry_chunk<false, 1, kD0, true>(cy, min(64, cy.count), lane, nodes, geoms);
-      }
-    } else if (near_scene) {
-      trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
-    } else {
-      w.best[lane] = kNoHit;
-    }
-    flush_deferred(df, qbase, out, rt, b);  // the previous chunk's survivors (see Deferred)
-    const unsigned long long best = w.best[lane];
+  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
+  // shading + retirement + compaction of one group of primary rays from its resolved hit key / record
+  auto shade_group = [&](unsigned long long best, const float* rec, bool valid, int k, int pl, int slot, uint32_t phash, f3 d) {
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
     ShadeIO s;
     s.o = o;
@@ -1660,13 +1655,13 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
         ht = __uint_as_float((uint32_t)(best >> 32));
         const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
         hmat = G->material;
-        hn = mk(w.rec[0 * 64 + lane], w.rec[1 * 64 + lane], w.rec[2 * 64 + lane]);
-        hp = mk(w.rec[3 * 64 + lane], w.rec[4 * 64 + lane], w.rec[5 * 64 + lane]);
+        hn = mk(rec[0 * 64], rec[1 * 64], rec[2 * 64]);
+        hp = mk(rec[3 * 64], rec[4 * 64], rec[5 * 64]);
         if (GRID) hn = Ar<kD0>::finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
     }
-    df.res = retire_and_reserve<true>(valid, s, k, pl, rt, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    df.res = retire_and_reserve<true>(valid, s, k, pl, rt, counter, lane);
     const bool alive = valid && s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
     df.s = s;
@@ -1674,6 +1669,68 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     df.alive = alive;
     df.dead = valid && !s.alive;
     df.any = true;
+  };
+  // a group between its search and its shading (RING)
+  struct {
+    f3 d;
+    int k, pl, slot;
+    uint32_t phash;
+    bool valid;
+    int par, mark;
+    bool any;
+  } pp;
+  pp.any = false;
+  Carry<true, 2> rc = carry_init<true, 2>(lds + tbl + wib * kWaveBytes);  // RING only (the same bytes as `w` otherwise)
+  rc.debug = b.debug;
+  rc.qo_tab = cam_qo;
+  int it = 0;
+  for (int j = r; j < entries; j += wq, ++it) {
+    int k, jj;
+    divmod(j, sh.my_nq, sh.inv_my_nq, k, jj);
+    const int pl_raw = (q + jj * qs.Q) * 64 + lane;
+    const bool valid = pl_raw < b.N;
+    const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
+    const int slot = make_slot(b, k, pl);
+    const int p = global_pixel(b, pl);  // global pixel index
+    const uint32_t phash = utilhash((uint32_t)p);  // rides along with the path from here on (kTagged)
+    float jx = 0.f, jy = 0.f;
+    if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
+    const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
+    // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
+    // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
+    // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
+    const bool near_scene = __ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+                                                   sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
+    if constexpr (RING) {
+      const int par = it & 1;
+      rc.best[par * 64 + lane] = kNoHit;
+      if (near_scene) carry_search<false, 2, true, kD0>(rc, cam_top, ntop, nodes, geoms, o, d, valid, lane, par, sc.cull_margin, sc.top_xor);
+      if (pp.any) carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
+      flush_deferred(df, qbase, out, rt, b);
+      if (pp.any) shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
+      pp.d = d, pp.k = k, pp.pl = pl, pp.slot = slot, pp.phash = phash, pp.valid = valid, pp.par = par, pp.mark = rc.appended, pp.any = true;
+    } else {
+      if (GRID) {
+        w.best[lane] = kNoHit;
+        if (near_scene) {
+          grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
+          while (cy.count > 0) carry_chunk<false, 1, kD0, true>(cy, min(64, cy.count), lane, nodes, geoms);
+        }
+      } else if (near_scene) {
+        trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
+      } else {
+        w.best[lane] = kNoHit;
+      }
+      flush_deferred(df, qbase, out, rt, b);  // the previous chunk's survivors (see Deferred)
+      shade_group(w.best[lane], w.rec + lane, valid, k, pl, slot, phash, d);
+    }
+  }
+  if constexpr (RING) {
+    if (pp.any) {
+      carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);
+      flush_deferred(df, qbase, out, rt, b);
+      shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
+    }
   }
   flush_deferred(df, qbase, out, rt, b);
   retire_end(rt, ret, b, q, r, lane);
@@ -2123,7 +2180,7 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       break;
     case kPrimary:
       if (use_big(sc) && sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false, true>, kBlock, primary_grid_lds_bytes(sc));
-      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, kWaveLds, true));
+      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kBounce:
@@ -2167,7 +2224,7 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                     const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf final_rgba) {
   if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
-  else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
+  else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
 }
 
