@@ -166,6 +166,26 @@ def test_striped_tiles_compose(scene_dir):
         assert np.array_equal(bits(out.reshape(-1, 3)), bits(full))
 
 
+@pytest.mark.parametrize("res,kw", [
+    ((640, 360), dict(num_queues=4)),                        # 900 chunks per queue: k_collect takes 8 passes of 128 chunks
+    ((640, 361), dict(num_queues=8, iters_per_batch=3)),     # odd row count: the tile's last chunk is partial; 3 batches + remainder
+    ((100, 7), dict(num_queues=256)),                        # 11 chunks for 256 queues: most queues own nothing
+    ((320, 200), dict(num_queues=16, blocks_per_cu=1, iters_per_batch=40)),
+    ((320, 200), dict(num_queues=32, unfused_bounces=True)),  # retirement from k_shade, wider grids: other waves-per-queue counts
+    ((320, 200), dict(num_queues=32, unfused_primary=True, iters_per_batch=5)),
+])
+def test_retirement_records_and_collect_layouts(scene_dir, res, kw):
+    """The retirement path (ptd::RetireBuf: queues own fixed pixel chunks, wave-private record segments, k_collect's LDS
+    tile and iteration-ordered sums) at shapes the default runs do not reach: more chunks per queue than one LDS tile
+    (multi-pass collect), partial last chunks, empty queues, few / many waves per queue, retirement from the unfused
+    shading kernel.  The image must not depend on any of it, bit for bit."""
+    spp = 10
+    ref, _ = gpu_render(scene_dir["cornell"], res, spp)
+    img, st = gpu_render(scene_dir["cornell"], res, spp, **kw)
+    assert st.samples == res[0] * res[1] * spp
+    assert np.array_equal(bits(img), bits(ref)), kw
+
+
 def test_clear_restarts_the_accumulation(scene_dir):
     """pt_clear: SUM image and statistics back to zero on the same buffers — what follows equals a fresh renderer's
     output bit for bit (bench.py warms up and measures on one renderer this way)."""
