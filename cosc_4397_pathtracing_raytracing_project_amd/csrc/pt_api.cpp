@@ -487,27 +487,34 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   } else {
     k.generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g, g.grid_gen), g.buf[0], g.d_cnt);
   }
-  for (int d = d0; d < g.depth; ++d) {
+  // debug_flags 1024: two bounces per pass in the fused bounce kernel of the small scenes (same image; measured 4-5 %
+  // slower than one per pass, DESIGN.md section 5, so not the default): the input alternates between the two path buffers
+  // per LAUNCH, not per depth
+  int src = d0 & 1;
+  for (int d = d0; d < g.depth;) {
     const int32_t* cin = g.d_cnt + per_depth * d;
-    int32_t* cout = g.d_cnt + per_depth * (d + 1);
+    int32_t* cmid = g.d_cnt + per_depth * (d + 1);
     EventPair ev{};
     if (g.time_kernels) {  // brackets the dominant kernel of this depth
       if (get_events(g, &ev)) return -1;
       HIP_OK(hipEventRecord(ev.a, g.stream));
     }
+    int covered = 1;
     if (g.fuse_bounces) {
-      k.bounce(g.stream, g.grid_bounce, sc, b, d, queues_for(g, g.grid_bounce), cin, cout, g.buf[d & 1], g.buf[(d + 1) & 1],
-               g.ret);
+      const int want = ((g.debug_flags & 1024) && d + 2 <= g.depth) ? 2 : 1;
+      int32_t* cout = g.d_cnt + per_depth * std::min(d + 2, g.depth);
+      covered = k.bounce(g.stream, g.grid_bounce, sc, b, d, want, queues_for(g, g.grid_bounce), cin, cmid, cout, g.buf[src], g.buf[src ^ 1], g.ret);
     } else {
-      k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[d & 1], g.hits, g.legacy, d == 0);
+      k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[src], g.hits, g.legacy, d == 0);
     }
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
       g.pending_isect.push_back(ev);
     }
     if (!g.fuse_bounces)
-      k.shade(g.stream, g.grid_shade, sc, b, d, queues_for(g, g.grid_shade), cin, cout, g.buf[d & 1], g.hits, g.buf[(d + 1) & 1],
-              g.ret);
+      k.shade(g.stream, g.grid_shade, sc, b, d, queues_for(g, g.grid_shade), cin, cmid, g.buf[src], g.hits, g.buf[src ^ 1], g.ret);
+    d += covered;
+    src ^= 1;
   }
   if (getenv("PT_DUMP_QUEUE_BALANCE")) {  // diagnostics: fill levels of the queues per depth (before k_count_stats zeroes them)
     HIP_OK(hipStreamSynchronize(g.stream));

@@ -96,9 +96,12 @@ struct KernelApi {
   // queues), retired samples to final_rgba; cnt0 receives the per-queue sample counts (statistics only).
   void (*primary)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                   const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf ret);
-  // Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.
-  void (*bounce)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
-                 const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret);
+  // Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.  levels = 2 asks for two bounces per pass
+  // (the survivors of the input queue's groups are traced once more from registers, pt_kernels.hip RegGroup): the return
+  // value says how many depths the launch covered (2 only from the small-scene kernel).  cnt_mid = fill-level row of
+  // depth + 1 (receives ray counts only when two depths are covered), cnt_out = row of depth + 2.
+  int (*bounce)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, int levels, const ptd::Queues& qs,
+                const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret);
   // computeIntersections over the live paths of every queue.  exact_arith: these are primary rays (depth 0), which
   // are traced with the reference's exact arithmetic in every mode (pt_kernels.hip, namespace ex).
   void (*intersect)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,

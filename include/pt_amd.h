@@ -100,7 +100,9 @@ typedef struct PtOptions {
                                near-first subtree order, 64 / 128 force the pipelined / the high-occupancy depth >= 1
                                kernel for scenes whose tables are not in LDS (default: by BVH size), 256 / 512 force /
                                forbid the uniform-grid walk of the fused kernels (default: for large scenes, whichever of
-                               grid and BVH scan renders one iteration faster at pt_init).  Bits 0-3 are profiling ablations with WRONG results
+                               grid and BVH scan renders one iteration faster at pt_init), 1024 two bounces per pass in the fused
+                               bounce kernel of small scenes (the survivors of every other depth stay in registers instead of
+                               going through HBM; measured slower, kept as an experiment).  Bits 0-3 are profiling ablations with WRONG results
                                (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
                                they exist only in -DPT_ABLATE builds of the library (tools/pmc_ablate.sh) and
                                pt_init fails on them otherwise (pt_library_has_ablations()).  (Environment,

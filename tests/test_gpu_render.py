@@ -173,6 +173,8 @@ def test_striped_tiles_compose(scene_dir):
     ((320, 200), dict(num_queues=16, blocks_per_cu=1, iters_per_batch=40)),
     ((320, 200), dict(num_queues=32, unfused_bounces=True)),  # retirement from k_shade, wider grids: other waves-per-queue counts
     ((320, 200), dict(num_queues=32, unfused_primary=True, iters_per_batch=5)),
+    ((320, 200), dict(debug_flags=1024)),                     # two bounces per pass: depths 1+2, 3+4, 5+6, 7
+    ((320, 200), dict(debug_flags=1024, iters_per_batch=7, num_queues=16)),
 ])
 def test_retirement_records_and_collect_layouts(scene_dir, res, kw):
     """The retirement path (ptd::RetireBuf: queues own fixed pixel chunks, wave-private record segments, k_collect's LDS
@@ -180,9 +182,10 @@ def test_retirement_records_and_collect_layouts(scene_dir, res, kw):
     (multi-pass collect), partial last chunks, empty queues, few / many waves per queue, retirement from the unfused
     shading kernel.  The image must not depend on any of it, bit for bit."""
     spp = 10
-    ref, _ = gpu_render(scene_dir["cornell"], res, spp)
+    ref, rst = gpu_render(scene_dir["cornell"], res, spp)
     img, st = gpu_render(scene_dir["cornell"], res, spp, **kw)
     assert st.samples == res[0] * res[1] * spp
+    assert list(st.live_rays[:8]) == list(rst.live_rays[:8]), kw  # also for depths whose paths never reached memory (1024)
     assert np.array_equal(bits(img), bits(ref)), kw
 
 
