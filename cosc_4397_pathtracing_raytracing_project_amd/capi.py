@@ -70,7 +70,7 @@ class PtStats(C.Structure):
                 ("intersect_ms", C.c_double), ("render_ms", C.c_double), ("num_cus", C.c_int32),
                 ("grid_blocks", C.c_int32), ("num_queues", C.c_int32), ("iters_per_batch", C.c_int32),
                 ("device_bytes", C.c_int64), ("primary_fused", C.c_int32), ("bounces_fused", C.c_int32),
-                ("arith", C.c_int32), ("grid_cells", C.c_int32)]
+                ("arith", C.c_int32), ("grid_cells", C.c_int32), ("tight_leaves", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class PtError(RuntimeError):
@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
     L.pt_scene_image_name.restype = C.c_char_p
     L.pt_build_bvh.argtypes = [C.POINTER(PtGeom), C.c_int, C.POINTER(PtBVHNode), C.c_int]
     L.pt_build_grid.argtypes = [C.POINTER(PtGeom), C.c_int, C.c_int, C.POINTER(PtGridInfo), C.POINTER(C.c_uint32), C.POINTER(PtGridRecord)]
+    if hasattr(L, "pt_traversal_boxes"):  # absent from older A/B builds of the library (tools/build_rev.sh)
+        L.pt_traversal_boxes.argtypes = [C.POINTER(PtGeom), C.c_int, _fp, _fp]
     L.pt_build_transform.argtypes = [_fp, _fp, _fp, _fp]
     L.pt_init.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions)]
     L.pt_render.argtypes = [C.c_int, C.c_int]
@@ -218,6 +220,16 @@ class Scene:
         recs = (PtGridRecord * info.num_records)()
         lib().pt_build_grid(self.desc.geoms, self.desc.num_geoms, int(forced), C.byref(info), start, recs)
         return info, np.frombuffer(start, np.uint32).copy(), recs
+
+    def traversal_boxes(self):
+        """(boxes [num_geoms, 6], tightened count): the leaf boxes the traversal structures of a LARGE scene test
+        (pt_traversal_boxes; sphere leaves tightened to the ellipsoid's box for ray origins in the scene or at the camera)."""
+        boxes = np.zeros((self.desc.num_geoms, 6), np.float32)
+        cam = np.asarray(list(self.desc.camera.position), np.float32)
+        rc = lib().pt_traversal_boxes(self.desc.geoms, self.desc.num_geoms, _f(cam), _f(boxes))
+        if rc < 0:
+            raise PtError(lib().pt_last_error().decode(errors="replace"))
+        return boxes, rc
 
     def bvh(self):
         n = lib().pt_build_bvh(self.desc.geoms, self.desc.num_geoms, None, 0)

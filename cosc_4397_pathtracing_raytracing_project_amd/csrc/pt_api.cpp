@@ -99,6 +99,7 @@ struct PtContext {
   int grid_res[3] = {0, 0, 0};
   float grid_min[3] = {0, 0, 0}, grid_cs[3] = {0, 0, 0}, grid_inv_cs[3] = {0, 0, 0}, grid_pad = 0.f;
   bool have_grid = false;
+  int tight_leaves = 0;  // sphere leaves with a tightened traversal box (tighten_sphere_leaves)
   bool grid_enabled = true;      // the outcome of choose_traversal()
   float probe_ms[2] = {0.f, 0.f};  // one iteration with the BVH scan / with the grid, as timed by choose_traversal()
   int cap_bpc = 8;
@@ -274,6 +275,93 @@ void box_normal_table(const float invT12[12], float out[7][4]) {
 void pack_rows(const float m16[16], float out12[12]) {
   for (int c = 0; c < 4; ++c)
     for (int r = 0; r < 3; ++r) out12[c * 3 + r] = m16[c * 4 + r];
+}
+
+// Tighter leaf boxes for spheres (large scenes only; result-neutral).  The reference's leaf box is the box of the
+// transformed unit CUBE (pathtrace.cu:36-50), which for a rotated sphere / ellipsoid is up to sqrt(3) wider per axis than
+// the primitive: rays pass the box, reach sphereIntersectionTest (intersections.h:102-144) and miss.  Our structures may
+// skip such a leaf exactly when its primitive test cannot report a hit, so the box our traversal tests is
+//     reference leaf box  INTERSECTED WITH  box of the ellipsoid { x : |A (x - c)| <= rho },  A = the geom's inverse transform,
+// where rho > 0.5 covers everything the reference's float arithmetic can still call a hit.  That test takes
+// radicand = v*v - (|ro|^2 - 0.25) >= 0 with ro = A o + t, rd = normalize(A d), v = ro . rd in float (u = 2^-24):
+//   * the two dot products, the square and the two subtractions:  <= 18 u |ro|^2,         |ro| <= |A|_F * D  =: D_obj
+//   * rounding of ro itself (4 products per component, cancelling against t when the object is far from the origin):
+//     |d ro| <= 14 u (|A|_F * M + |t|) =: 14 u M_obj, which moves the squared distance to the axis by <= 2 * 0.5 * |d ro|
+//   * rounding of rd (direction error <= 5 u cond(A)), which moves it by <= 5 u cond(A) * D_obj
+// with D = the largest distance from a ray origin to the sphere's centre and M = the largest coordinate magnitude of a ray
+// origin; ray origins of the renderer lie in the scene bounds (hit points) or at the camera.  rho^2 = 0.25 + 4 x that sum
+// (safety factor 3.5 on the dominant term), the box is rounded outward and padded by 32 float-eps of M for the slab test's
+// own rounding.  The tightened box lies inside the reference's, so a ray that passes it passes the reference's box and
+// every ancestor (the slab test is monotone under inclusion): the leaves we test are a subset of the
+// reference's, and the ones we drop return "no hit" there.  Exact mode stays bit-identical (tests: stress scenes and the
+// random-scene fuzz against the oracle, which keeps the reference's boxes); debug_flags 2048 keeps the reference's boxes.
+// pt_stage_intersect on such a scene inherits the assumption about ray origins.
+// One sphere: ref_lo / ref_hi = the reference's leaf box; returns false when nothing could be tightened.
+bool sphere_tight_box(const PtGeom& gm, const double origin_lo[3], const double origin_hi[3], const float ref_lo[3], const float ref_hi[3],
+                      float lo[3], float hi[3]) {
+  const double u = 1.0 / 16777216.0;
+  double M = 0.0;
+  for (int a = 0; a < 3; ++a) M = std::max({M, std::fabs(origin_lo[a]), std::fabs(origin_hi[a])});
+  M *= std::sqrt(3.0);
+  const float* inv = gm.inverseTransform;  // column-major 4x4, m[c*4+r]
+  double A[3][3], t[3], B[3][3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) A[r][c] = inv[c * 4 + r];
+    t[r] = inv[3 * 4 + r];
+  }
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      const int r1 = (c + 1) % 3, r2 = (c + 2) % 3, c1 = (r + 1) % 3, c2 = (r + 2) % 3;  // B = A^-1: cofactor of A[c][r] over det
+      B[r][c] = (A[r1][c1] * A[r2][c2] - A[r1][c2] * A[r2][c1]) / det;
+    }
+  double nA = 0.0, nB = 0.0, nt = 0.0, ctr[3], D = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) nA += A[r][c] * A[r][c], nB += B[r][c] * B[r][c];
+    nt += t[r] * t[r];
+    ctr[r] = -(B[r][0] * t[0] + B[r][1] * t[1] + B[r][2] * t[2]);
+  }
+  nA = std::sqrt(nA), nB = std::sqrt(nB), nt = std::sqrt(nt);
+  for (int a = 0; a < 3; ++a) {
+    const double far = std::max(std::fabs(ctr[a] - origin_lo[a]), std::fabs(ctr[a] - origin_hi[a]));
+    D += far * far;
+  }
+  const double D_obj = nA * std::sqrt(D), M_obj = nA * M + nt;
+  const double rho = std::sqrt(0.25 + 4.0 * u * (18.0 * D_obj * D_obj + 14.0 * M_obj + 5.0 * nA * nB * D_obj));
+  if (!std::isfinite(rho)) return false;
+  const double slab = 32.0 * (double)FLT_EPSILON * M;
+  bool changed = false;
+  for (int a = 0; a < 3; ++a) {
+    const double half = rho * std::sqrt(B[a][0] * B[a][0] + B[a][1] * B[a][1] + B[a][2] * B[a][2]) + slab;
+    lo[a] = std::nextafterf((float)(ctr[a] - half), -INFINITY);
+    hi[a] = std::nextafterf((float)(ctr[a] + half), INFINITY);
+    if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) lo[a] = ref_lo[a], hi[a] = ref_hi[a];
+    lo[a] = std::max(lo[a], ref_lo[a]), hi[a] = std::min(hi[a], ref_hi[a]);
+    changed = changed || lo[a] != ref_lo[a] || hi[a] != ref_hi[a];
+  }
+  return changed && lo[0] < hi[0] && lo[1] < hi[1] && lo[2] < hi[2];
+}
+int tighten_sphere_leaves(std::vector<ptd::Node>& nodes, const std::vector<PtGeom>& geoms, const double origin_lo[3], const double origin_hi[3]) {
+  int tightened = 0;
+  for (ptd::Node& n : nodes) {
+    if (n.geom < 0 || geoms[n.geom].type != PT_GEOM_SPHERE) continue;
+    float lo[3], hi[3];
+    if (!sphere_tight_box(geoms[n.geom], origin_lo, origin_hi, n.bmin, n.bmax, lo, hi)) continue;
+    std::memcpy(n.bmin, lo, 12);
+    std::memcpy(n.bmax, hi, 12);
+    ++tightened;
+  }
+  return tightened;
+}
+// The region ray origins come from: hit points (inside the scene bounds; the shading offsets are <= 1e-3) and the camera.
+void origin_region(const float root_min[3], const float root_max[3], const float cam[3], double olo[3], double ohi[3]) {
+  for (int a = 0; a < 3; ++a) {
+    const double ext = (double)root_max[a] - (double)root_min[a];
+    olo[a] = std::min((double)root_min[a] - 0.01 * ext - 0.01, (double)cam[a]);
+    ohi[a] = std::max((double)root_max[a] + 0.01 * ext + 0.01, (double)cam[a]);
+  }
 }
 
 // Uniform grid over the leaf boxes — the traversal structure of our own for large scenes (SceneTables::grid_*).  The
@@ -726,6 +814,14 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   g.num_top = (int)top.size();
   std::memcpy(g.root_min, ref_nodes[0].bmin, 12);
   std::memcpy(g.root_max, ref_nodes[0].bmax, 12);
+  g.tight_leaves = 0;
+  if (g.num_nodes >= kGridNodes && !(opt.debug_flags & 2048)) {
+    double olo[3], ohi[3];
+    origin_region(g.root_min, g.root_max, g.cam.position, olo, ohi);
+    g.tight_leaves = tighten_sphere_leaves(nodes, g.geoms, olo, ohi);
+    for (ptd::TopEntry& e : top)
+      if (e.link < 0) std::memcpy(e.bmin, nodes[e.idx].bmin, 12), std::memcpy(e.bmax, nodes[e.idx].bmax, 12);
+  }
   {
     // SceneTables::cull_margin: >= 10x the worst undershoot of a reported hit distance (1e-4 object units mapped
     // to world space + rounding of the transforms at the scene's coordinate magnitudes)
@@ -860,6 +956,28 @@ int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap) {
   pt::buildBVH(geoms, num_geoms, nodes);
   if (out) std::memcpy(out, nodes.data(), sizeof(PtBVHNode) * std::min<size_t>(nodes.size(), (size_t)std::max(cap, 0)));
   return (int)nodes.size();
+}
+
+int pt_traversal_boxes(const PtGeom* geoms, int num_geoms, const float camera_position[3], float* boxes) {
+  if (!geoms || num_geoms <= 0 || !camera_position || !boxes) return fail("pt_traversal_boxes: null argument");
+  std::vector<PtBVHNode> ref_nodes;
+  pt::buildBVH(geoms, num_geoms, ref_nodes);
+  double olo[3], ohi[3];
+  origin_region(ref_nodes[0].bmin, ref_nodes[0].bmax, camera_position, olo, ohi);
+  int tightened = 0;
+  for (const PtBVHNode& n : ref_nodes) {
+    if (n.left >= 0) continue;
+    float* b = boxes + 6 * (size_t)n.geomIndex;
+    std::memcpy(b, n.bmin, 12);
+    std::memcpy(b + 3, n.bmax, 12);
+    float lo[3], hi[3];
+    if (geoms[n.geomIndex].type == PT_GEOM_SPHERE && sphere_tight_box(geoms[n.geomIndex], olo, ohi, n.bmin, n.bmax, lo, hi)) {
+      std::memcpy(b, lo, 12);
+      std::memcpy(b + 3, hi, 12);
+      ++tightened;
+    }
+  }
+  return tightened;
 }
 
 int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records) {
@@ -1036,6 +1154,8 @@ int pt_ctx_get_stats(PtContext* c, PtStats* out) {
   out->bounces_fused = g.fuse_bounces ? 1 : 0;
   out->arith = g.arith;
   out->grid_cells = (tables(g).use_grid && g.fuse_bounces) ? g.grid_res[0] * g.grid_res[1] * g.grid_res[2] : 0;
+  out->tight_leaves = g.tight_leaves;
+  out->reserved0 = 0;
   return 0;
 }
 

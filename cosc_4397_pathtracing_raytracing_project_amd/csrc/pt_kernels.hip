@@ -1315,17 +1315,20 @@ template <bool EX>
 constexpr bool stored_rinv() { return EX || !kFastDiv; }
 template <bool EX>
 constexpr int grid_wave_bytes() { return carry_bytes<false, 1>() + kCellRing * 4 + kRing * 4 + (stored_rinv<EX>() ? 3 * 64 * 4 : 0); }  // Carry + cell ring + Carry::gix (+ CellRing::rinv)
-// Exclusive prefix sum over the wave of a small count (< 64) per lane, and the total: one ballot per bit.
+// Exclusive prefix sum over the wave of a small count per lane, and the total: a Hillis-Steele scan on the DPP network —
+// four row_shr steps scan each row of 16 lanes, row_bcast:15 / :31 carry the row totals over — six v_add_u32_dpp instead of
+// the six ballots + twelve mbcnt + six shift-adds of a bit-sliced count (round 2; the walk loop runs this once per cell step).
+// All 64 lanes must be active (the callers' control flow is wave-uniform).
 PT_DEV int wave_prefix6(int v, int& total) {
-  int pre = 0;
-  total = 0;
-#pragma unroll
-  for (int b = 0; b < 6; ++b) {
-    const unsigned long long m = __ballot((v >> b) & 1);
-    pre += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)) << b;
-    total += __popcll(m) << b;
-  }
-  return pre;
+  int x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1, zero shifted in
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8: inclusive scan of each row
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  total = __builtin_amdgcn_readlane(x, 63);
+  return x - v;
 }
 // Leaf-box tests (the mode's slab arithmetic: these decide, exactly like the reference's walk, which primitives a ray is
 // tested against) for the first n (<= 64) pending records; passing leaves go to the primitive ring.  A leaf that is also
@@ -1477,6 +1480,7 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
       const unsigned long long nm = __ballot(now);
       if (nm) cr.count += __builtin_amdgcn_readlane(pre + want, 63 - __builtin_clzll(nm));
       while (cr.count >= 64) grid_filter<NPAR, EX>(c, cr, 64, sc, lane, nodes, geoms);
+      if (!__ballot(it != se.y)) break;  // the usual case: every list went in at once — no second pass to find that out
     }
     // next cell: through the nearest boundary
     const bool ax = w.tx <= w.ty && w.tx <= w.tz;

@@ -102,7 +102,9 @@ typedef struct PtOptions {
                                forbid the uniform-grid walk of the fused kernels (default: for large scenes, whichever of
                                grid and BVH scan renders one iteration faster at pt_init), 1024 two bounces per pass in the fused
                                bounce kernel of small scenes (the survivors of every other depth stay in registers instead of
-                               going through HBM; measured slower, kept as an experiment).  Bits 0-3 are profiling ablations with WRONG results
+                               going through HBM; measured slower, kept as an experiment), 2048 keep the reference's
+                               leaf boxes for spheres (default for large scenes: tightened to the ellipsoid's box, PtStats.tight_leaves;
+                               pt_stage_intersect on such a scene then expects ray origins inside the scene bounds or at the camera).  Bits 0-3 are profiling ablations with WRONG results
                                (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
                                they exist only in -DPT_ABLATE builds of the library (tools/pmc_ablate.sh) and
                                pt_init fails on them otherwise (pt_library_has_ablations()).  (Environment,
@@ -154,6 +156,9 @@ typedef struct PtStats {
   int32_t arith;                      /* PT_ARITH_* in use                                               */
   int32_t grid_cells;                 /* > 0: the fused kernels walk the uniform grid over the leaf boxes (large scenes on
                                          which it beat the BVH scan at pt_init) with this many cells; 0: the BVH         */
+  int32_t tight_leaves;               /* sphere leaves whose traversal box was tightened from the reference's box of the
+                                         transformed unit cube to the box of the ellipsoid (large scenes; same image)     */
+  int32_t reserved0;
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,
@@ -189,7 +194,15 @@ typedef struct PtGridInfo {
 typedef struct PtGridRecord {
   float bmin[3], bmax[3]; /* the leaf's box (the reference's worldBounds)                                     */
   int32_t leaf;           /* index of the leaf in the reference's visiting order (threaded BVH)              */
-  int32_t neighbours;     /* bits 0-5: the leaf is also listed in the neighbour cell -x, +x, -y, +y, -z, +z;
+  int32_t neighbours;     /* Host-only: the box our traversal structures test for each geom's leaf — the reference's leaf box (pathtrace.cu:36-50),
+ * except for spheres of large scenes, where it is intersected with the box of the ellipsoid itself (grown by a bound on
+ * what sphereIntersectionTest's float arithmetic, intersections.h:102-144, can still report as a hit for ray origins inside
+ * the scene bounds or at `camera_position`; csrc/pt_api.cpp sphere_tight_box).  A ray that passes the tightened box passes the
+ * reference's; a ray that passes only the reference's misses the sphere: same hits, fewer candidates.  boxes[g] = {min xyz, max xyz}.
+ * Returns the number of tightened leaves (pt_init applies it from 1024 BVH nodes on; PtOptions.debug_flags 2048 turns it off). */
+int pt_traversal_boxes(const PtGeom* geoms, int num_geoms, const float camera_position[3], float* boxes);
+
+/* bits 0-5: the leaf is also listed in the neighbour cell -x, +x, -y, +y, -z, +z;
                              bits 6-7: primitive type; bits 8-31: index of the primitive in PtSceneDesc.geoms  */
 } PtGridRecord;
 int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records);
