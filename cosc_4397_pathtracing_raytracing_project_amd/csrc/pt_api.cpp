@@ -95,6 +95,7 @@ struct PtContext {
   int lds_table_bytes = -1;        // SceneTables::lds_table_bytes
   // uniform grid over the leaf boxes (build_grid; SceneTables::grid_*), large scenes where it beats the BVH scan (choose_traversal)
   uint32_t* d_grid_start = nullptr;
+  size_t grid_guard = 0;  // empty cells in front of (and behind) the cell table proper
   ptd::Node* d_grid_items = nullptr;
   int grid_res[3] = {0, 0, 0};
   float grid_min[3] = {0, 0, 0}, grid_cs[3] = {0, 0, 0}, grid_inv_cs[3] = {0, 0, 0}, grid_pad = 0.f;
@@ -520,7 +521,7 @@ ptk::SceneTables tables(const Ctx& g) {
   if (t.use_grid) {
     t.big_kernel = 1;
     t.lds_table_bytes = -1;  // (a forced grid on a small scene: the big kernel reads the tables from memory)
-    t.grid_start = g.d_grid_start;
+    t.grid_start = g.d_grid_start + g.grid_guard;
     t.grid_items = g.d_grid_items;
     for (int a = 0; a < 3; ++a)
       t.grid_res[a] = g.grid_res[a], t.grid_min[a] = g.grid_min[a], t.grid_cs[a] = g.grid_cs[a], t.grid_inv_cs[a] = g.grid_inv_cs[a];
@@ -880,8 +881,14 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
     double cam_mag = 0.0;
     for (int a = 0; a < 3; ++a) cam_mag = std::max(cam_mag, std::fabs((double)g.cam.position[a]));
     if (build_grid(nodes, g.geoms, g.root_min, g.root_max, cam_mag, dens ? atof(dens) : 0.0, (g.debug_flags & 256) != 0, gb)) {
-      if (dalloc(g, &g.d_grid_start, gb.start.size()) || dalloc(g, &g.d_grid_items, gb.items.size())) return -1;
-      HIP_OK(hipMemcpy(g.d_grid_start, gb.start.data(), gb.start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      // the cell table with empty cells before and after it: a walk may run up to one cell per axis past the grid's far side
+      // before its distance test ends it (pt_kernels.hip CellWalk)
+      g.grid_guard = (size_t)gb.res[0] * gb.res[1] + gb.res[0] + 2;
+      std::vector<uint32_t> padded(gb.start.size() + 2 * g.grid_guard, 0u);
+      std::copy(gb.start.begin(), gb.start.end(), padded.begin() + g.grid_guard);
+      std::fill(padded.begin() + g.grid_guard + gb.start.size(), padded.end(), gb.start.back());
+      if (dalloc(g, &g.d_grid_start, padded.size()) || dalloc(g, &g.d_grid_items, gb.items.size())) return -1;
+      HIP_OK(hipMemcpy(g.d_grid_start, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(g.d_grid_items, gb.items.data(), gb.items.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
       for (int a = 0; a < 3; ++a)
         g.grid_res[a] = gb.res[a], g.grid_min[a] = gb.gmin[a], g.grid_cs[a] = gb.cs[a], g.grid_inv_cs[a] = gb.inv_cs[a];

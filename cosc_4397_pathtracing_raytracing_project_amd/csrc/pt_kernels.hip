@@ -94,6 +94,22 @@ constexpr bool kAblate = true;
 constexpr bool kAblate = false;
 #endif
 
+// Diagnostic builds only (-DPT_WALK_STATS, tools/walk_stats.py): event counts of the large-scene kernels' search loops, added up
+// over a launch in a buffer nothing else reads.  The product build compiles none of it.
+#ifdef PT_WALK_STATS
+__device__ unsigned long long g_walk_stats[16];
+#define PT_STAT(i, v)                                                             \
+  do {                                                                            \
+    if (lane_id() == 0) atomicAdd(&g_walk_stats[i], (unsigned long long)(v));     \
+  } while (0)
+PT_DEV int wave_max_stat(int v) {
+  for (int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+#else
+#define PT_STAT(i, v)
+#endif
+
 // Tuning switch of the large-scene (global-table) path, overridable with -D for A/B builds.
 #ifndef PT_STEAL_MIN
 #define PT_STEAL_MIN 16
@@ -1145,6 +1161,8 @@ template <bool SMALL, int NPAR, bool EX = false, bool LEAN = false, bool QO = fa
 PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node* __restrict__ nodes,
                         const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
+  PT_STAT(6, 1);
+  PT_STAT(7, n);
   const int idx = (c.head + lane) & (kRing - 1);
   const uint32_t entry = (uint32_t)c.ent[idx];
   const int src = (int)(entry & 63u);
@@ -1305,16 +1323,17 @@ constexpr int kCellRing = 256;  // entries (power of two): what is left of a ste
 struct CellRing {
   uint32_t* ent;  // [kCellRing]
   int head, count;
-  float* rinv;    // [3][64] reciprocal direction of each lane's ray (the mode's arithmetic), computed once per ray
+  float* rinv;    // [rinv_planes][64] reciprocal direction of each lane's ray in the mode's arithmetic (+ -o * that: fast)
 };
-// The reciprocal direction the box tests need costs three IEEE divides per ray in the exact and fma arithmetic: there it is
-// computed once per ray and kept in LDS (CellRing::rinv) instead of once per record; the fast mode's three v_rcp are
-// cheaper than the LDS round trip (measured: stored reciprocals make the fast bounce kernel 34 % slower, the exact and
-// fma ones 6 % faster).
+// What the leaf-box tests need of a ray is computed once per ray and kept in LDS (CellRing::rinv) instead of once per record
+// (a group tests ~950 records, 15 per ray): the reciprocal direction — three IEEE divides in the exact and fma arithmetic —
+// and, where the slab test has the FMA form t = plane * i + n (fast), n = -o * i as well, so that a record's test reads six
+// values and computes no reciprocal.  (Round 2 measured the stored reciprocals 34 % slower for the fast build of the kernel
+// as it was then; round 3, with the retirement and filing changes in: 3.4 % faster, `n` included 6 %.)
 template <bool EX>
-constexpr bool stored_rinv() { return EX || !kFastDiv; }
+constexpr int rinv_planes() { return (EX || !kFastSlab) ? 3 : 6; }
 template <bool EX>
-constexpr int grid_wave_bytes() { return carry_bytes<false, 1>() + kCellRing * 4 + kRing * 4 + (stored_rinv<EX>() ? 3 * 64 * 4 : 0); }  // Carry + cell ring + Carry::gix (+ CellRing::rinv)
+constexpr int grid_wave_bytes() { return carry_bytes<false, 1>() + kCellRing * 4 + kRing * 4 + rinv_planes<EX>() * 64 * 4; }  // Carry + cell ring + Carry::gix + CellRing::rinv
 // Exclusive prefix sum over the wave of a small count per lane, and the total: a Hillis-Steele scan on the DPP network —
 // four row_shr steps scan each row of 16 lanes, row_bcast:15 / :31 carry the row totals over — six v_add_u32_dpp instead of
 // the six ballots + twelve mbcnt + six shift-adds of a bit-sliced count (round 2; the walk loop runs this once per cell step).
@@ -1338,22 +1357,25 @@ template <int NPAR, bool EX = false>
 PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneTables& sc, int lane,
                         const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
+  PT_STAT(4, 1);
+  PT_STAT(5, n);
   const uint32_t entry = cr.ent[(cr.head + lane) & (kCellRing - 1)];
   const int src = (int)(entry & 63u);
   const int par = (int)((entry >> 6) & 1u);
   const int from = (int)((entry >> 7) & 7u);
   const uint32_t item = valid ? entry >> 10 : 0u;
-  const float* ray = c.ray + par * 6 * 64 + src;
-  const f3 ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
   const float4 NA = reinterpret_cast<const float4*>(sc.grid_items)[2 * item];      // bmin.xyz, bmax.x
   const float4 NB = reinterpret_cast<const float4*>(sc.grid_items)[2 * item + 1];  // bmax.yz, leaf, neighbour bits
-  RayInv ri;
-  if (stored_rinv<EX>()) {  // as ray_inv() builds it, from the stored reciprocals: the divides are per ray, not per record
-    ri.ix = cr.rinv[0 * 64 + src], ri.iy = cr.rinv[1 * 64 + src], ri.iz = cr.rinv[2 * 64 + src];
-    ri.sx = ri.ix < 0.0f, ri.sy = ri.iy < 0.0f, ri.sz = ri.iz < 0.0f;
-    ri.nx = -ro.x * ri.ix, ri.ny = -ro.y * ri.iy, ri.nz = -ro.z * ri.iz;
+  RayInv ri;  // as ray_inv() builds it, from the values stored once per ray
+  f3 ro = mk(0.f, 0.f, 0.f);
+  ri.ix = cr.rinv[0 * 64 + src], ri.iy = cr.rinv[1 * 64 + src], ri.iz = cr.rinv[2 * 64 + src];
+  ri.sx = ri.ix < 0.0f, ri.sy = ri.iy < 0.0f, ri.sz = ri.iz < 0.0f;
+  if (rinv_planes<EX>() == 6) {  // FMA form: the origin itself is not needed
+    ri.nx = cr.rinv[3 * 64 + src], ri.ny = cr.rinv[4 * 64 + src], ri.nz = cr.rinv[5 * 64 + src];
   } else {
-    ri = Ar<EX>::ray_inv(mk(ray[3 * 64], ray[4 * 64], ray[5 * 64]), ro);
+    const float* ray = c.ray + par * 6 * 64 + src;
+    ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
+    ri.nx = -ro.x * ri.ix, ri.ny = -ro.y * ri.iy, ri.nz = -ro.z * ri.iz;
   }
   const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + src) + 1]) + sc.cull_margin;
   float tn;
@@ -1362,15 +1384,26 @@ PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneT
   const bool pass = valid && !seen && Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
   cr.head = (cr.head + n) & (kCellRing - 1);
   cr.count -= n;
+#ifdef PT_WALK_STATS
+  const int st_seen = __popcll(__ballot(valid && seen)), st_pass = __popcll(__ballot(pass));
+  const int st_box = __popcll(__ballot(valid && !seen && Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn)));
+  PT_STAT(10, st_seen);
+  PT_STAT(11, st_pass);
+  PT_STAT(12, st_box);
+#endif
   carry_append<false, NPAR, EX, true>(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms,
                                       (bits >> 8) | (((bits >> 6) & 3u) << 30));
 }
 // State of a lane's cell walk (3D-DDA): the distance along the ray of the next cell boundary per axis, the distance
-// between boundaries, the cells left before the grid ends, the current cell.
+// between boundaries, the current cell.  A walk ends by distance alone (te > t_end, the grid's far side): the boundary
+// distances accumulate rounding, so the decision at the exit face can come a step late — up to three steps at a corner of
+// the grid — and the cell index then leaves the grid by at most one cell per axis, i.e. by < rx * ry + rx + 2 entries of
+// the cell table: the host pads the table with that many empty cells on both sides (pt_api.cpp), and a wrapped index
+// inside the table only adds records to test (round 2 counted the cells left per axis instead: 3 registers and 6
+// instructions per step).
 struct CellWalk {
   float tx, ty, tz, ddx, ddy, ddz;
-  int lx, ly, lz;
-  bool fx, fy, fz;  // moving towards +x / +y / +z
+  int px, py, pz;  // per axis: cell-index step << 3 | face the next cell is entered through (0..5 = its -x, +x, -y, +y, -z, +z face)
   int idx;
   float te, t_end;  // entry distance of the current cell; the walk covers [te, t_end]
   uint32_t from;    // face the current cell was entered through (grid_filter), 7: first cell of a walk
@@ -1399,12 +1432,15 @@ PT_DEV void walk_start(const SceneTables& sc, f3 o, f3 d, float t_from, float t_
   const int cx = min(max((int)__builtin_floorf((px - gx) * sc.grid_inv_cs[0]), 0), rx - 1);
   const int cy = min(max((int)__builtin_floorf((py - gy) * sc.grid_inv_cs[1]), 0), ry - 1);
   const int cz = min(max((int)__builtin_floorf((pz - gz) * sc.grid_inv_cs[2]), 0), rz - 1);
-  w.fx = dx >= 0.0f, w.fy = dy >= 0.0f, w.fz = dz >= 0.0f;
-  w.tx = (gx + csx * (float)(cx + (w.fx ? 1 : 0)) - o.x) * ix;
-  w.ty = (gy + csy * (float)(cy + (w.fy ? 1 : 0)) - o.y) * iy;
-  w.tz = (gz + csz * (float)(cz + (w.fz ? 1 : 0)) - o.z) * iz;
+  const bool fx = dx >= 0.0f, fy = dy >= 0.0f, fz = dz >= 0.0f;  // moving towards +x / +y / +z
+  w.tx = (gx + csx * (float)(cx + (fx ? 1 : 0)) - o.x) * ix;
+  w.ty = (gy + csy * (float)(cy + (fy ? 1 : 0)) - o.y) * iy;
+  w.tz = (gz + csz * (float)(cz + (fz ? 1 : 0)) - o.z) * iz;
   w.ddx = csx * __builtin_fabsf(ix), w.ddy = csy * __builtin_fabsf(iy), w.ddz = csz * __builtin_fabsf(iz);
-  w.lx = w.fx ? rx - 1 - cx : cx, w.ly = w.fy ? ry - 1 - cy : cy, w.lz = w.fz ? rz - 1 - cz : cz;
+  const int rxy = rx * ry;
+  w.px = fx ? 8 + 0 : -8 + 1;  // moving +x: the next cell is entered through its -x face  (step = word >> 3, face = word & 7)
+  w.py = fy ? 8 * rx + 2 : -8 * rx + 3;
+  w.pz = fz ? 8 * rxy + 4 : -8 * rxy + 5;
   w.idx = cx + rx * (cy + ry * cz);
   w.te = t_in;
   w.t_end = t_out;
@@ -1427,13 +1463,14 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
   float* rays = c.ray + par * 6 * 64;
   rays[0 * 64 + lane] = o.x, rays[1 * 64 + lane] = o.y, rays[2 * 64 + lane] = o.z;
   rays[3 * 64 + lane] = d.x, rays[4 * 64 + lane] = d.y, rays[5 * 64 + lane] = d.z;
-  if (stored_rinv<EX>()) {
+  {
     const RayInv ri = Ar<EX>::ray_inv(d, o);
     cr.rinv[0 * 64 + lane] = ri.ix, cr.rinv[1 * 64 + lane] = ri.iy, cr.rinv[2 * 64 + lane] = ri.iz;
+    if (rinv_planes<EX>() == 6) cr.rinv[3 * 64 + lane] = ri.nx, cr.rinv[4 * 64 + lane] = ri.ny, cr.rinv[5 * 64 + lane] = ri.nz;
   }
   CellWalk w;
+  PT_STAT(0, 1);
   walk_start(sc, o, d, 0.0f, FLT_MAX, valid, lane, w);
-  const int rx = sc.grid_res[0], rxy = sc.grid_res[0] * sc.grid_res[1];
   const float slack = sc.cull_margin + 2.0f * sc.grid_pad;
   int splits = 0;
   while (true) {
@@ -1441,6 +1478,8 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
     w.on = w.on && !(w.te > bt) && !(w.te > w.t_end);
     const unsigned long long M = __ballot(w.on);
     if (!M) break;
+    PT_STAT(1, 1);
+    PT_STAT(2, __popcll(M));
     if (kGridSplit > 0 && splits < 2 && __popcll(M) <= kGridSplit) {
       ++splits;
       const int n_on = __popcll(M);
@@ -1473,6 +1512,12 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
       if (total == 0) break;
       const bool now = pre + want <= kCellRing - 64;
       const int take = now ? want : 0;
+#ifdef PT_WALK_STATS
+      const int st_trips = wave_max_stat(take), st_lanes = __popcll(__ballot(take > 0));
+      PT_STAT(3, 1);
+      PT_STAT(8, st_trips);
+      PT_STAT(9, st_lanes);
+#endif
       const int base = cr.head + cr.count + pre;
       for (int j = 0; j < take; ++j) cr.ent[(base + j) & (kCellRing - 1)] = ((it + (uint32_t)j) << 10) | tag;
       it += (uint32_t)take;
@@ -1483,16 +1528,15 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
       if (!__ballot(it != se.y)) break;  // the usual case: every list went in at once — no second pass to find that out
     }
     // next cell: through the nearest boundary
-    const bool ax = w.tx <= w.ty && w.tx <= w.tz;
-    const bool ay = !ax && w.ty <= w.tz;
-    const int left = ax ? w.lx : ay ? w.ly : w.lz;
-    if (left == 0) w.on = false;
-    w.te = ax ? w.tx : ay ? w.ty : w.tz;
-    w.idx += ax ? (w.fx ? 1 : -1) : ay ? (w.fy ? rx : -rx) : (w.fz ? rxy : -rxy);
-    w.from = ax ? (w.fx ? 0u : 1u) : ay ? (w.fy ? 2u : 3u) : (w.fz ? 4u : 5u);  // moving +x: entered through the -x face
-    if (ax) w.tx += w.ddx, --w.lx;
-    else if (ay) w.ty += w.ddy, --w.ly;
-    else w.tz += w.ddz, --w.lz;
+    w.te = __builtin_fminf(__builtin_fminf(w.tx, w.ty), w.tz);
+    const bool ax = w.tx == w.te;
+    const bool ay = !ax && w.ty == w.te;
+    const int step = ax ? w.px : ay ? w.py : w.pz;
+    w.idx += step >> 3;
+    w.from = (uint32_t)step & 7u;
+    if (ax) w.tx += w.ddx;
+    else if (ay) w.ty += w.ddy;
+    else w.tz += w.ddz;
   }
   while (cr.count > 0) grid_filter<NPAR, EX>(c, cr, min(64, cr.count), sc, lane, nodes, geoms);
 }
@@ -2360,5 +2404,18 @@ const KernelApi kApi = {
 }  // namespace PT_NS
 
 const KernelApi* PT_API_FN() { return &PT_NS::kApi; }
+
+#if defined(PT_WALK_STATS) && PT_ARITH == 2
+}  // namespace ptk
+// diagnostic builds only: the fast build's counters since the last call (read and reset)
+extern "C" int pt_debug_walk_stats(unsigned long long* out) {
+  unsigned long long zero[16] = {0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptk::arith_fast::g_walk_stats), sizeof(zero)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ptk::arith_fast::g_walk_stats), zero, sizeof(zero)) != hipSuccess) return -1;
+  return 16;
+}
+namespace ptk {
+#endif
 
 }  // namespace ptk
