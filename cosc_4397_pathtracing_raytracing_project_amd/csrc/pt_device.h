@@ -78,10 +78,10 @@ struct Camera {
 // memory instructions and ten 64-bit address computations each way; the kernels are bound by instruction issue):
 //   plane 0   origin.xyz, direction.x
 //   plane 1   direction.yz, colour.xy
-//   plane 2   colour.z | slot: sample id inside the batch, k*N + p (k = iteration in batch, p = tile pixel) |
-//             utilhash(global pixel index): the per-pixel half of makeSeededRandomEngine's seed (pathtrace.cu:205), computed
-//             once per sample at depth 0 instead of once per ray and depth | k
-// 48 B per path (40 B of algorithmic state + the carried hash and iteration: 8 B that save a division and a hash per bounce).
+//   plane 2   colour.z | sample id inside the batch: k << slot_shift | tile pixel (BatchInfo::slot_shift), 8 B per path
+// 40 B per path, the algorithmic minimum of SURVEY §8(d) (+ 0: the id replaces the reference's pixelIndex).  -DPT_REC_TAGGED
+// widens plane 2 to 16 B with utilhash(global pixel index) and k carried along (saves a hash and a shift per bounce; measured
+// 10-20 % SLOWER — the bounce kernel's time follows its bytes — so it is not the default).
 struct alignas(16) Word4 {
   float x, y, z, w;
 };

@@ -93,7 +93,7 @@ struct KernelApi {
   void (*generate)(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
                    ptd::PathBuf out, int32_t* cnt0);
   // Depth 0 fused (generate + intersect + shade + compaction): survivors go to `out` / cnt_out (the depth-1
-  // queues), retired samples to final_rgba; cnt0 receives the per-queue sample counts (statistics only).
+  // queues), retired samples to the retirement records `ret`; cnt0 receives the per-queue sample counts (statistics only).
   void (*primary)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                   const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf ret);
   // Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.  levels = 2 asks for two bounces per pass

@@ -9,13 +9,15 @@
 //   k_shade      shadeAndExtendRays      src/pathtrace.cu:336-437 (+ helpers :216-242,
 //                RNG :203-207, utilhash intersections.h:12-20) fused with the retirement
 //                rule of SURVEY.md §8a and the compaction the reference never had
-//   k_gather     finalGather             src/pathtrace.cu:439-444
+//   k_collect    finalGather             src/pathtrace.cu:439-444 (sums the retirement records, pt_device.h RetireBuf,
+//                into the image in iteration order)
 //   k_preview    sendImageToPBO          src/pathtrace.cu:250-268
 //   k_save_u8    saveImage + savePNG     src/main.cpp:86-107, src/image.cpp:22-39
 // and the two kernels the default pipeline actually runs, which fuse the above per depth so that
 // neither the primary ray nor the hit record ever goes through HBM:
 //   k_primary    depth 0:  generate + intersect + shade + compaction
 //   k_bounce     depth >= 1: intersect + shade + compaction, candidate ring carried across groups
+//   k_bounce_big the same for scenes whose tables do not fit LDS: uniform grid walk (grid_search) or BVH scan
 // (k_generate / k_intersect / k_shade remain as the unfused form for stage-parity tests and A/B runs,
 // k_intersect_legacy as the per-lane tree walk the wave-cooperative search replaced.)
 //
@@ -2327,36 +2329,36 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
 }
 
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
-                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf final_rgba) {
-  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
-  else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, final_rgba);
+                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf ret) {
+  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
+  else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
 }
 
 // levels: bounces per pass the caller asks for (1 or 2); returns how many the launched kernel performs — 2 only from
 // k_bounce (the large-scene kernels trace one depth per pass) — so that the host advances its depth loop by that much.
 // cnt_mid: fill-level row of depth + 1 (two bounces per pass: receives the ray count only), cnt_out: row of depth + levels.
 int launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, int levels, const ptd::Queues& qs,
-                  const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf final_rgba) {
-  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL(k_bounce_big<true>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, final_rgba);
-  else if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big<false>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, final_rgba);
+                  const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
+  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL(k_bounce_big<true>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
+  else if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big<false>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
   else if (tables_in_lds(sc) && levels > 1) {  // the LDS-table kernel, two bounces per pass (on request: measured slower)
-    hipLaunchKernelGGL((k_bounce<true, true>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()) + iter_hash_entries(sc) * 4, s, sc, b, depth, 2, qs, cnt_in, cnt_mid, cnt_out, in, out, final_rgba);
+    hipLaunchKernelGGL((k_bounce<true, true>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()) + iter_hash_entries(sc) * 4, s, sc, b, depth, 2, qs, cnt_in, cnt_mid, cnt_out, in, out, ret);
     return 2;
   } else if (tables_in_lds(sc)) {
-    hipLaunchKernelGGL((k_bounce<true, false>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, 1, qs, cnt_in, cnt_mid, cnt_mid, in, out, final_rgba);
+    hipLaunchKernelGGL((k_bounce<true, false>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, 1, qs, cnt_in, cnt_mid, cnt_mid, in, out, ret);
   } else {
-    hipLaunchKernelGGL((k_bounce<false, false>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, carry_bytes<false>()), s, sc, b, depth, 1, qs, cnt_in, cnt_mid, cnt_mid, in, out, final_rgba);
+    hipLaunchKernelGGL((k_bounce<false, false>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, carry_bytes<false>()), s, sc, b, depth, 1, qs, cnt_in, cnt_mid, cnt_mid, in, out, ret);
   }
   return 1;
 }
 
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                  ptd::RetireBuf final_rgba) {
+                  ptd::RetireBuf ret) {
   const int bytes = retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4;
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
-                     final_rgba);
+                     ret);
 }
 
 int flat_grid(int n, int cap) {
