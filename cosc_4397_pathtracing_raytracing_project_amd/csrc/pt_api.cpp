@@ -100,9 +100,20 @@ struct PtContext {
   int grid_res[3] = {0, 0, 0};
   float grid_min[3] = {0, 0, 0}, grid_cs[3] = {0, 0, 0}, grid_inv_cs[3] = {0, 0, 0}, grid_pad = 0.f;
   bool have_grid = false;
+  // Grids of other resolutions built next to the host's first choice; choose_traversal() times them all, keeps the fastest
+  // in the fields above and frees the rest.
+  struct GridAlt {
+    uint32_t* d_start;
+    size_t guard;
+    ptd::Node* d_items;
+    int res[3];
+    float gmin[3], cs[3], inv_cs[3], pad;
+    size_t bytes;
+  };
+  std::vector<GridAlt> grid_alts;
   int tight_leaves = 0;  // sphere leaves with a tightened traversal box (tighten_sphere_leaves)
   bool grid_enabled = true;      // the outcome of choose_traversal()
-  float probe_ms[2] = {0.f, 0.f};  // one iteration with the BVH scan / with the grid, as timed by choose_traversal()
+  float probe_ms[2] = {0.f, 0.f};  // a few iterations with the BVH scan / with the (fastest) grid, as timed by choose_traversal()
   int cap_bpc = 8;
   bool legacy = false;
   int debug_flags = 0;
@@ -641,14 +652,36 @@ void plan_launch(Ctx& g) {
   g.grid_bounce = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounce, t));
 }
 
-// Grid or BVH scan?  Both give the same image; which is faster depends on how the primitives are
-// spread and how far rays fly, and no count of references predicted it across lattice, random and clustered scenes — so
-// it is measured: up to 8 iterations of the context's own tile with each (the second of two runs counts), before the
-// first sample is rendered.  Costs a few tens of milliseconds for a 1080p tile.  debug_flags 256 / 512 skip the measurement.
+// Make candidate i the grid the kernels walk.
+void use_grid_alt(Ctx& g, size_t i) {
+  const Ctx::GridAlt& a = g.grid_alts[i];
+  g.d_grid_start = a.d_start, g.grid_guard = a.guard, g.d_grid_items = a.d_items;
+  for (int k = 0; k < 3; ++k) g.grid_res[k] = a.res[k], g.grid_min[k] = a.gmin[k], g.grid_cs[k] = a.cs[k], g.grid_inv_cs[k] = a.inv_cs[k];
+  g.grid_pad = a.pad;
+  g.have_grid = true;
+}
+// Grid or BVH scan, and which grid?  All give the same image; which is faster depends on how the
+// primitives are spread and how far rays fly, and no count of references predicted it across lattice, random and clustered
+// scenes — so it is measured: up to 8 iterations of the context's own tile with each (the second of two runs counts), before
+// the first sample is rendered.  Costs a few tens of milliseconds per candidate for a 1080p tile.  debug_flags 256 / 512 skip
+// the measurement.
 int choose_traversal(Ctx& g) {
-  if (!g.have_grid || !g.fuse_bounces || (g.debug_flags & (256 | 512 | 64))) return 0;
-  for (int v = 0; v < 2; ++v) {
-    g.grid_enabled = v == 1;
+  auto drop_unused_grids = [&](size_t keep) {
+    for (size_t i = 0; i < g.grid_alts.size(); ++i) {
+      if (i == keep) continue;
+      for (void* p : {(void*)g.grid_alts[i].d_start, (void*)g.grid_alts[i].d_items}) {
+        (void)hipFree(p);
+        g.allocs.erase(std::remove(g.allocs.begin(), g.allocs.end(), p), g.allocs.end());
+      }
+      g.device_bytes -= (int64_t)g.grid_alts[i].bytes;
+    }
+    g.grid_alts.clear();
+  };
+  if (!g.have_grid || !g.fuse_bounces || (g.debug_flags & (256 | 512 | 64))) {
+    if (g.have_grid) drop_unused_grids(0);
+    return 0;
+  }
+  auto time_one = [&](float* ms) -> int {
     plan_launch(g);
     for (int rep = 0; rep < 2; ++rep) {
       EventPair ev{};
@@ -657,10 +690,24 @@ int choose_traversal(Ctx& g) {
       if (run_batch(g, 1, std::min(g.K, 8))) return -1;  // enough groups per wave for the persistent grids to fill
       HIP_OK(hipEventRecord(ev.b, g.stream));
       HIP_OK(hipStreamSynchronize(g.stream));
-      HIP_OK(hipEventElapsedTime(&g.probe_ms[v], ev.a, ev.b));
+      HIP_OK(hipEventElapsedTime(ms, ev.a, ev.b));
       g.free_events.push_back(ev);
     }
+    return 0;
+  };
+  g.grid_enabled = false;
+  if (time_one(&g.probe_ms[0])) return -1;
+  g.grid_enabled = true;
+  size_t best = 0;
+  for (size_t i = 0; i < g.grid_alts.size(); ++i) {
+    float ms = 0.f;
+    use_grid_alt(g, i);
+    if (time_one(&ms)) return -1;
+    // a finer grid has to beat the model's by 3 %, so that the choice does not flip between runs on timing noise
+    if (i == 0 || ms < 0.97f * g.probe_ms[1]) g.probe_ms[1] = ms, best = i;
   }
+  use_grid_alt(g, best);
+  drop_unused_grids(best);
   // the grid has to win by a margin: two short timed runs on a shared or noisy box differ by a few per cent, and a
   // choice that flips between runs makes PtStats and profiles irreproducible; results are equal either way
   g.grid_enabled = g.probe_ms[1] < 0.95f * g.probe_ms[0];
@@ -876,25 +923,39 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
   if ((g.num_nodes >= kGridNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
-    GridBuild gb;
     const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive instead of the search
     double cam_mag = 0.0;
     for (int a = 0; a < 3; ++a) cam_mag = std::max(cam_mag, std::fabs((double)g.cam.position[a]));
-    if (build_grid(nodes, g.geoms, g.root_min, g.root_max, cam_mag, dens ? atof(dens) : 0.0, (g.debug_flags & 256) != 0, gb)) {
+    // Candidates: the resolution the host's cost model finds (about one cell per primitive; build_grid) and two finer ones.
+    // The model prices a uniform spread of primitives and rays; where the primitives cluster, a finer grid pays (clustered 1500
+    // objects: 2319 Msamples/s at the model's resolution, 2931 at 8 cells per primitive; a lattice wants exactly its pitch),
+    // so choose_traversal() measures.  A forced grid (debug_flags 256) or a forced density is the only candidate.
+    const bool forced = (g.debug_flags & 256) != 0;
+    std::vector<double> densities{dens ? atof(dens) : 0.0};
+    if (!forced && !dens) densities.insert(densities.end(), {4.0, 8.0});
+    for (double density : densities) {
+      GridBuild gb;
+      if (!build_grid(nodes, g.geoms, g.root_min, g.root_max, cam_mag, density, forced, gb)) continue;
+      bool repeat = false;
+      for (const Ctx::GridAlt& o : g.grid_alts) repeat = repeat || (o.res[0] == gb.res[0] && o.res[1] == gb.res[1] && o.res[2] == gb.res[2]);
+      if (repeat) continue;
+      Ctx::GridAlt alt{};
       // the cell table with empty cells before and after it: a walk may run up to one cell per axis past the grid's far side
       // before its distance test ends it (pt_kernels.hip CellWalk)
-      g.grid_guard = (size_t)gb.res[0] * gb.res[1] + gb.res[0] + 2;
-      std::vector<uint32_t> padded(gb.start.size() + 2 * g.grid_guard, 0u);
-      std::copy(gb.start.begin(), gb.start.end(), padded.begin() + g.grid_guard);
-      std::fill(padded.begin() + g.grid_guard + gb.start.size(), padded.end(), gb.start.back());
-      if (dalloc(g, &g.d_grid_start, padded.size()) || dalloc(g, &g.d_grid_items, gb.items.size())) return -1;
-      HIP_OK(hipMemcpy(g.d_grid_start, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-      HIP_OK(hipMemcpy(g.d_grid_items, gb.items.data(), gb.items.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
-      for (int a = 0; a < 3; ++a)
-        g.grid_res[a] = gb.res[a], g.grid_min[a] = gb.gmin[a], g.grid_cs[a] = gb.cs[a], g.grid_inv_cs[a] = gb.inv_cs[a];
-      g.grid_pad = gb.pad;
-      g.have_grid = true;
+      alt.guard = (size_t)gb.res[0] * gb.res[1] + gb.res[0] + 2;
+      std::vector<uint32_t> padded(gb.start.size() + 2 * alt.guard, 0u);
+      std::copy(gb.start.begin(), gb.start.end(), padded.begin() + alt.guard);
+      std::fill(padded.begin() + alt.guard + gb.start.size(), padded.end(), gb.start.back());
+      const int64_t before = g.device_bytes;
+      if (dalloc(g, &alt.d_start, padded.size()) || dalloc(g, &alt.d_items, gb.items.size())) return -1;
+      alt.bytes = (size_t)(g.device_bytes - before);
+      HIP_OK(hipMemcpy(alt.d_start, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      HIP_OK(hipMemcpy(alt.d_items, gb.items.data(), gb.items.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
+      for (int a = 0; a < 3; ++a) alt.res[a] = gb.res[a], alt.gmin[a] = gb.gmin[a], alt.cs[a] = gb.cs[a], alt.inv_cs[a] = gb.inv_cs[a];
+      alt.pad = gb.pad;
+      g.grid_alts.push_back(alt);
     }
+    if (!g.grid_alts.empty()) use_grid_alt(g, 0);
   }
 
   g.cap_bpc = opt.blocks_per_cu > 0 ? std::min(opt.blocks_per_cu, 8) : 8;
