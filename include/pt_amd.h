@@ -100,7 +100,7 @@ typedef struct PtOptions {
                                near-first subtree order, 64 / 128 force the pipelined / the high-occupancy depth >= 1
                                kernel for scenes whose tables are not in LDS (default: by BVH size), 256 / 512 force /
                                forbid the uniform-grid walk of the fused kernels (default: for large scenes, whichever of
-                               grid and BVH scan renders one iteration faster at pt_init), 1024 two bounces per pass in the fused
+                               the BVH scan and up to three grid resolutions renders a few iterations fastest at pt_init), 1024 two bounces per pass in the fused
                                bounce kernel of small scenes (the survivors of every other depth stay in registers instead of
                                going through HBM; measured slower, kept as an experiment), 2048 keep the reference's
                                leaf boxes for spheres (default for large scenes: tightened to the ellipsoid's box, PtStats.tight_leaves;
@@ -181,9 +181,10 @@ int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap);
  * the BVH.  The image is the same either way: a primitive is tested exactly when the ray passes the primitive's own box
  * test, and every leaf is listed in all cells its box, grown by `pad`, touches.  A scene is a CANDIDATE when it has
  * >= 1024 BVH nodes and its lists stay moderate (at most 64 cell references per primitive; `forced` skips both
- * conditions, as PtOptions.debug_flags 256 does); for a candidate pt_init / pt_ctx_create time one iteration of the
- * tile with the grid and one with the BVH scan and keep the faster (PtStats.grid_cells > 0: the grid).  This function is
- * host-only (no GPU needed).  Returns 1 and fills `info` for a candidate, 0 otherwise, -1 on error; cell c's records
+ * conditions, as PtOptions.debug_flags 256 does); for a candidate pt_init / pt_ctx_create time a few iterations of the
+ * tile with the BVH scan, with this grid and with two finer ones (4 and 8 cells per primitive) and keep the fastest
+ * (PtStats.grid_cells > 0: a grid, with that many cells).  The device walks the same structure over the boxes of
+ * pt_traversal_boxes, its cell table padded with empty guard cells.  This function is host-only (no GPU needed).  Returns 1 and fills `info` for a candidate, 0 otherwise, -1 on error; cell c's records
  * are records[cell_start[c] .. cell_start[c + 1]), c = x + res[0] * (y + res[1] * z); either array may be NULL (sizes
  * are in `info`). */
 typedef struct PtGridInfo {
@@ -194,18 +195,18 @@ typedef struct PtGridInfo {
 typedef struct PtGridRecord {
   float bmin[3], bmax[3]; /* the leaf's box (the reference's worldBounds)                                     */
   int32_t leaf;           /* index of the leaf in the reference's visiting order (threaded BVH)              */
-  int32_t neighbours;     /* Host-only: the box our traversal structures test for each geom's leaf — the reference's leaf box (pathtrace.cu:36-50),
+  int32_t neighbours;     /* bits 0-5: the leaf is also listed in the neighbour cell -x, +x, -y, +y, -z, +z;
+                             bits 6-7: primitive type; bits 8-31: index of the primitive in PtSceneDesc.geoms  */
+} PtGridRecord;
+int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records);
+
+/* Host-only: the box our traversal structures test for each geom's leaf — the reference's leaf box (pathtrace.cu:36-50),
  * except for spheres of large scenes, where it is intersected with the box of the ellipsoid itself (grown by a bound on
  * what sphereIntersectionTest's float arithmetic, intersections.h:102-144, can still report as a hit for ray origins inside
  * the scene bounds or at `camera_position`; csrc/pt_api.cpp sphere_tight_box).  A ray that passes the tightened box passes the
  * reference's; a ray that passes only the reference's misses the sphere: same hits, fewer candidates.  boxes[g] = {min xyz, max xyz}.
  * Returns the number of tightened leaves (pt_init applies it from 1024 BVH nodes on; PtOptions.debug_flags 2048 turns it off). */
 int pt_traversal_boxes(const PtGeom* geoms, int num_geoms, const float camera_position[3], float* boxes);
-
-/* bits 0-5: the leaf is also listed in the neighbour cell -x, +x, -y, +y, -z, +z;
-                             bits 6-7: primitive type; bits 8-31: index of the primitive in PtSceneDesc.geoms  */
-} PtGridRecord;
-int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records);
 
 /* transform / inverse / inverse-transpose of an OBJECT block's TRANS ROTAT SCALE
  * (trs[9]), as utilityCore::buildTransformationMatrix + glm::inverse +

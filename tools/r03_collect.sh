@@ -10,4 +10,6 @@ cp $S/kstats/t_kernel_stats.csv $P/r03_kernel_stats.csv
 cp $S/kernel_stats_bench_line.json $P/r03_kernel_stats_bench_line.json
 cp $S/bench_driver_style_20spp.json $P/r03_bench_driver_style_20spp.json
 [ -f $S/bench_default_fast_5000spp_stress.json ] && cp $S/bench_default_fast_5000spp_stress.json $P/r03_bench_default_fast_5000spp_stress.json
+[ -f $S/c5_grid_pmc_summary_fast.txt ] && cp $S/c5_grid_pmc_summary_fast.txt $P/r03_c5_grid_pmc_summary_fast.txt
+[ -f $S/c5_pmc/trace/t_kernel_stats.csv ] && cp $S/c5_pmc/trace/t_kernel_stats.csv $P/r03_c5_grid_kernel_stats_fast.csv
 ls -la $P/r03_* $P/dominant_kernel_traffic.json

@@ -25,4 +25,8 @@ timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_dri
 if [ -z "$QUICK" ]; then
   timeout -k 10 600 python3 bench.py --stress > $O/bench_default_fast_5000spp_stress.json 2> $O/bench_default.err
 fi
+# 5. C5 (10,170 primitives): kernel stats + PMC passes, grid forced so that the init-time probe adds no launches
+(cd /tmp && timeout -k 10 500 bash $R/tools/pmc_config.sh $O/c5_pmc stress --spp 100 --arith fast --debug-flags 256 > $R/$O/c5_pmc.log 2>&1)
+python3 tools/pmc_summary.py $O/c5_pmc > $O/c5_grid_pmc_summary_fast.txt 2>&1
+rm -f $O/c5_pmc/pass*/*.db $O/c5_pmc/trace/*.db
 ls $O | head -40
