@@ -131,3 +131,54 @@ def test_striped_tiles_on_the_grid_compose(scene_dir):
         for rank in range(world):
             out[rank::world] = render(**parallel.striped_tile_for_rank(w, h, rank, world)).reshape(-1, w, 3)
         assert np.array_equal(bits(out.reshape(-1, 3)), bits(full))
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_init_time_choice_among_structures_never_changes_the_image(oracle, tmp_path, clustered):
+    """pt_init times the BVH scan, the cost model's grid and two finer grids on a large scene and keeps the fastest
+    (choose_traversal); sphere leaves are tested against their tightened boxes (PtStats.tight_leaves).  Whatever it picks:
+    the exact-mode image equals the oracle's — which walks the reference's tree over the reference's boxes — bit for bit, and
+    equals the images with the grid forced / forbidden and with the reference's boxes kept (debug_flags 2048)."""
+    res, spp = (240, 160), 3
+    path = scenes.write_scene(scenes.random_scene_text(31 + clustered, 1400, res=res, depth=8, clustered=clustered), str(tmp_path / "r.txt"))
+    sc = capi.Scene(path, res=res)
+    imgs, tight = {}, {}
+    for flags in (0, 256, 512, 2048, 256 | 2048):
+        r = capi.Renderer(sc, debug_flags=flags)
+        try:
+            r.render(1, spp)
+            imgs[flags] = r.readback()
+            st = r.stats()
+            tight[flags] = st.tight_leaves
+            if flags & 256:
+                assert st.grid_cells > 0
+            if flags & 512:
+                assert st.grid_cells == 0
+        finally:
+            r.free()
+    assert tight[0] > 300 and tight[256] == tight[0] and tight[2048] == 0 and tight[256 | 2048] == 0
+    oracle.set_math_mode(oracle.PORTABLE)
+    oracle.load_scene(path, res=res)
+    ref = oracle.render(1, spp, depth=8, variant=oracle.RETIRE, nthreads=min(16, os.cpu_count() or 1))
+    for flags, img in imgs.items():
+        assert np.array_equal(bits(img), bits(ref)), f"debug_flags {flags}"
+
+
+@pytest.mark.parametrize("arith", ["fma", "fast"])
+def test_tightened_sphere_leaves_do_not_change_fma_and_fast_images(tmp_path, arith):
+    """The tightened boxes are sized for the float slop of the sphere test in the reference's arithmetic (x 4); the fma / fast
+    tests round differently but no worse: same image with the reference's boxes (debug_flags 2048), grid and scan."""
+    res, spp = (320, 200), 4
+    path = scenes.write_scene(scenes.stress_scene_text((12, 12, 10), res=res), str(tmp_path / "s.txt"))
+    sc = capi.Scene(path, res=res)
+    imgs = []
+    for flags in (256, 256 | 2048, 512, 512 | 2048):
+        r = capi.Renderer(sc, debug_flags=flags, arith=arith)
+        try:
+            r.render(1, spp)
+            imgs.append(r.readback())
+            assert (r.stats().tight_leaves > 0) == (not flags & 2048)
+        finally:
+            r.free()
+    for im in imgs[1:]:
+        assert np.array_equal(bits(imgs[0]), bits(im))
