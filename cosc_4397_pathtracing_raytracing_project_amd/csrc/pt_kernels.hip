@@ -87,6 +87,16 @@ constexpr bool kFast = PT_ARITH == 2;
 #ifndef PT_FAST_RENORM
 #define PT_FAST_RENORM 1  // getPointOnRay does not normalise the already normalised object-space direction again
 #endif
+#ifndef PT_FAST_POINT
+#define PT_FAST_POINT 0   // 1: hit point as ray origin + direction * world distance instead of transform * object-space point (the
+                          // object-space direction is normalize(inverse * d), so transform * it = d / |inverse * d|, and the world
+                          // distance is the object-space one times the rsq the normalisation already took): spares the 48-byte
+                          // `transform` fetch of every hit candidate — a dependent second fetch per chunk — and 9 FMAs.  Measured
+                          // (round 3): C5 bounce kernel -5.3 %, cornell -1 %; OFF because it is one more place where the fast
+                          // mode rounds differently from the reference, and the random-scene tolerance test then sees 0.27 % of
+                          // the pixels off by > 1e-5 against its bound of 0.2 % (tests/test_gpu_arith.py).  The tolerance wins.
+#endif
+constexpr bool kFastPoint = kFast && PT_FAST_POINT;
 constexpr bool kFastTrig = kFast && PT_FAST_TRIG, kFastDiv = kFast && PT_FAST_DIV, kFastSqrt = kFast && PT_FAST_SQRT,
                kFastSlab = kFast && PT_FAST_SLAB, kFastMV = kFast && PT_FAST_MV, kFastRenorm = kFast && PT_FAST_RENORM, kFastQO = PT_ARITH == 0 || (kFast && PT_FAST_QO);
 // Ablation switches of tools/pmc_ablate.sh (BatchInfo::debug, wrong results) exist only in -DPT_ABLATE builds.
@@ -167,7 +177,7 @@ struct RayInv {
 #pragma clang fp contract(off)
 namespace ex {
 namespace {
-constexpr bool kFastDiv = false, kFastSqrt = false, kFastMV = false, kFastRenorm = false, kFastSlab = false, kFastQO = true;
+constexpr bool kFastDiv = false, kFastSqrt = false, kFastMV = false, kFastRenorm = false, kFastSlab = false, kFastQO = true, kFastPoint = false;
 #include "pt_arith.inc"
 }  // namespace
 }  // namespace ex
@@ -177,7 +187,7 @@ constexpr bool kFastDiv = false, kFastSqrt = false, kFastMV = false, kFastRenorm
 namespace md {
 namespace {
 constexpr bool kFastDiv = PT_NS::kFastDiv, kFastSqrt = PT_NS::kFastSqrt, kFastMV = PT_NS::kFastMV, kFastRenorm = PT_NS::kFastRenorm,
-               kFastSlab = PT_NS::kFastSlab, kFastQO = PT_NS::kFastQO;
+               kFastSlab = PT_NS::kFastSlab, kFastQO = PT_NS::kFastQO, kFastPoint = PT_NS::kFastPoint;
 #include "pt_arith.inc"
 }  // namespace
 }  // namespace md
