@@ -81,7 +81,7 @@ enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3,
 //   0 exact  -ffp-contract=off, every operation in the reference's order: bit-identical to oracle/pt_oracle.cpp
 //            (PORTABLE mode) — the parity anchor;
 //   1 fma    the same source with FMA contraction allowed (what nvcc does to the reference by default), IEEE
-//            divide / sqrt kept;
+//            divide / sqrt kept, float-only direction sampling with accurate float sin / cos (ptmath::sincos_rev);
 //   2 fast   fma + hardware reciprocal / rsqrt / sqrt / sin / cos (all <= 1 ulp or ~1e-6 absolute), nested-FMA
 //            matrix products, float-only direction sampling.
 // Modes 1 and 2 are checked against the oracle's reference semantics (LIBM mode) with the tolerance of

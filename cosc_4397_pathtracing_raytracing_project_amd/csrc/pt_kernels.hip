@@ -26,7 +26,7 @@
 //            evaluate it, divisions and square roots are IEEE (hipcc default
 //            -fhip-fp32-correctly-rounded-divide-sqrt), and sin/cos/acos come from pt_portable_math.h, so
 //            results are bit-identical to oracle/pt_oracle.cpp in PORTABLE mode;
-//   1 fma:   the same source with contraction allowed;
+//   1 fma:   the same source with contraction allowed; direction sampling in float only (shade_bounce_float<false>);
 //   2 fast:  the `kFast` branches below — hardware rcp / rsq / sqrt / sin / cos, nested-FMA matrix products,
 //            float-only direction sampling.  Same algorithm, same RNG draws, same decisions; only rounding differs.
 // No MFMA: there is no dense contraction here.
@@ -97,6 +97,10 @@ constexpr bool kFast = PT_ARITH == 2;
                           // the pixels off by > 1e-5 against its bound of 0.2 % (tests/test_gpu_arith.py).  The tolerance wins.
 #endif
 constexpr bool kFastPoint = kFast && PT_FAST_POINT;
+#ifndef PT_FMA_FLOAT_TRIG
+#define PT_FMA_FLOAT_TRIG 1  // fma mode: float-only direction sampling (shade_bounce_float<false>) instead of the exact mode's
+#endif
+constexpr bool kFloatTrig = PT_ARITH == 1 && PT_FMA_FLOAT_TRIG;
 constexpr bool kFastTrig = kFast && PT_FAST_TRIG, kFastDiv = kFast && PT_FAST_DIV, kFastSqrt = kFast && PT_FAST_SQRT,
                kFastSlab = kFast && PT_FAST_SLAB, kFastMV = kFast && PT_FAST_MV, kFastRenorm = kFast && PT_FAST_RENORM, kFastQO = PT_ARITH == 0 || (kFast && PT_FAST_QO);
 // Ablation switches of tools/pmc_ablate.sh (BatchInfo::debug, wrong results) exist only in -DPT_ABLATE builds.
@@ -932,12 +936,18 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
   s.alive = (depth + 1) < trace_depth;
   return bo;
 }
-// Fast-mode direction sampling: the same draws and the same formulas, evaluated in float only.
-//   v_sin_f32 / v_cos_f32 take their argument in revolutions, so sin(2*pi*u) is one instruction on u itself;
+// Direction sampling of the fast and fma modes: the same draws and the same formulas, evaluated in float only.
+//   The trigonometric arguments are taken in REVOLUTIONS — sin(2*pi*u) of the draw u itself, and the specular angle
+//   roughness*u1*pi/2 = roughness*u1/4 revolutions — so no 2*pi*u is rounded to float first (the reference rounds it, then calls sinf);
 //   diffuse: cos(theta) = sqrt(1 - u1) =: s and sin(theta) = sin(acos(s)) = sqrt(1 - s*s) (one FMA keeps 1 - s*s exact
-//   to one rounding), so neither acos nor a sincos of theta is evaluated;
-//   specular: angle = roughness*u1*pi/2 = roughness*u1/4 revolutions.
-PT_DEV void shade_bounce_fast(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
+//   to one rounding), so neither acos nor a sincos of theta is evaluated.
+//   HW (fast): v_sin_f32 / v_cos_f32 take revolutions directly, v_sqrt_f32.
+//   !HW (fma): IEEE square roots and ptmath::sincos_rev (float polynomials, <= 1.6 ulp: the accuracy class of the sinf / cosf the
+//   reference runs on under nvcc, which documents 2 ulp); the specular evaluations only when the wave holds a specular lane.
+//   Round 3: the fma mode used to share the exact mode's sampling (fdlibm acosf + three double-reduced sincos, 900 issue cycles a
+//   group); it is held to the tolerance, not to bit-equality, and the tolerance does not see the difference (tests/test_gpu_arith.py).
+template <bool HW>
+PT_DEV void shade_bounce_float(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
   MinStd rng(1u);
   rng.x = bo.rng_x;
   const bool spec = bo.kind == 1;
@@ -945,12 +955,25 @@ PT_DEV void shade_bounce_fast(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
   const f3 refl = madd(hn, -2.0f * dot(s.d, hn), s.d);
   const f3 f = spec ? refl : hn;
   const float rev = bo.roughness * r1 * 0.25f;
-  const float ct = __builtin_amdgcn_sqrtf(1.0f - r1);
-  const float st = __builtin_amdgcn_sqrtf(__builtin_fmaxf(fma_(-ct, ct, 1.0f), 0.0f));
-  const float sX = spec ? __builtin_amdgcn_sinf(rev) : st;
-  const float cX = spec ? __builtin_amdgcn_cosf(rev) : ct;
-  const float c1 = __builtin_amdgcn_cosf(r2);
-  const float s2 = __builtin_amdgcn_sinf(spec ? r3 : r2);
+  const float ct = HW ? __builtin_amdgcn_sqrtf(1.0f - r1) : __builtin_sqrtf(1.0f - r1);
+  const float st2 = __builtin_fmaxf(fma_(-ct, ct, 1.0f), 0.0f);
+  const float st = HW ? __builtin_amdgcn_sqrtf(st2) : __builtin_sqrtf(st2);
+  float sA = 0.0f, cA = 1.0f, c1, s2;
+  if (HW) {
+    sA = __builtin_amdgcn_sinf(rev), cA = __builtin_amdgcn_cosf(rev);
+    c1 = __builtin_amdgcn_cosf(r2);
+    s2 = __builtin_amdgcn_sinf(spec ? r3 : r2);
+  } else {
+    ptmath::sincos_rev(r2, &s2, &c1);
+    if (__ballot(spec)) {  // wave-uniform
+      float s3, c3;
+      ptmath::sincos_rev(rev, &sA, &cA);
+      ptmath::sincos_rev(r3, &s3, &c3);
+      s2 = spec ? s3 : s2;
+    }
+  }
+  const float sX = spec ? sA : st;
+  const float cX = spec ? cA : ct;
   const float x = sX * c1, z = sX * s2, y = cX;
   f3 tangent, bitangent;
   local_frame(f, tangent, bitangent);
@@ -960,7 +983,8 @@ PT_DEV void shade_bounce_fast(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
   s.d = perturb ? pert : refl;
 }
 PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
-  if (kFastTrig) return shade_bounce_fast(bo, hn, hp, s);
+  if (kFastTrig) return shade_bounce_float<true>(bo, hn, hp, s);
+  if (kFloatTrig) return shade_bounce_float<false>(bo, hn, hp, s);
   // The specular branch (pathtrace.cu:402-422) and the diffuse branch (:424-435, :225-238) have the
   // same shape — a frame around an axis f, three trigonometric evaluations, normalize(t*x + f*y + b*z)
   // — so both are evaluated by ONE instruction stream with per-lane operands instead of two divergent

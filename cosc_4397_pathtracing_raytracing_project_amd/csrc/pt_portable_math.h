@@ -126,6 +126,42 @@ PT_HD float acosf32(float x) {
   return 2.0f * (df + w);
 }
 
+// sin(2 pi u) and cos(2 pi u) for u in [0, 1], float operations only — the fma arithmetic mode's direction sampling
+// (pt_kernels.hip shade_bounce_float).  The argument is taken in REVOLUTIONS, so the reduction is exact: k = rint(4u),
+// f = u - k/4 (one FMA, exact), |f| <= 1/8; r = 2 pi f is formed as a head + tail product (float(2 pi) and its remainder,
+// the head product's rounding recovered with an FMA), rounded once, and the tail of that sum corrects the results to first
+// order.  Same polynomials as sincos_r.  Measured against double-precision sin / cos over all 2^24 + 1 arguments i / 2^24
+// and 10^7 random ones (tests/test_portable_math.py): <= 1.5 ulp, i.e. inside what CUDA documents for the sinf / cosf
+// the reference itself runs on (2 ulp) and tighter than evaluating sinf on a 2 pi u that was rounded to float first.
+PT_HD void sincos_rev(float u, float* s_out, float* c_out) {
+  const float TWO_PI_HI = 6.2831854820251465f;   // float(2 pi)
+  const float TWO_PI_LO = -1.7484555e-07f;       // 2 pi - float(2 pi)
+  const float k = __builtin_rintf(4.0f * u);
+  const float f = fma32(k, -0.25f, u);
+  const float rh = f * TWO_PI_HI;
+  const float rl = fma32(f, TWO_PI_LO, fma32(f, TWO_PI_HI, -rh));  // what rh lost + the constant's tail
+  const float r = rh + rl;
+  const float rt = rl - (r - rh);  // tail of the sum (|rt| <= ulp(r) / 2)
+  const int q = ((int)k) & 3;
+  const float z = r * r;
+  const float S1 = -1.666666666e-01f, S2 = 8.333331871e-03f, S3 = -1.984008473e-04f, S4 = 2.724965793e-06f;
+  const float C1 = 4.166666666e-02f, C2 = -1.388888767e-03f, C3 = 2.480059866e-05f, C4 = -2.730073108e-07f;
+  float ps = fma32(z, S4, S3);
+  ps = fma32(z, ps, S2);
+  ps = fma32(z, ps, S1);
+  float pc = fma32(z, C4, C3);
+  pc = fma32(z, pc, C2);
+  pc = fma32(z, pc, C1);
+  const float c0 = fma32(z * z, pc, fma32(z, -0.5f, 1.0f));
+  const float s0 = fma32(r * z, ps, r);
+  const float s = fma32(rt, c0, s0);  // sin(r + rt) = sin r + rt cos r
+  const float c = fma32(-rt, s0, c0);
+  const float vs = (q & 1) ? c : s;
+  const float vc = (q & 1) ? s : c;
+  *s_out = (q & 2) ? -vs : vs;
+  *c_out = ((q + 1) & 2) ? -vc : vc;
+}
+
 // float wrappers (what the renderer calls where the reference calls the float overloads)
 PT_HD float sinf32(float x) { return sin_r((double)x); }
 PT_HD float cosf32(float x) { return cos_r((double)x); }

@@ -131,7 +131,8 @@ typedef struct PtOptions {
  *   EXACT  every operation in the reference's source order without FMA contraction, IEEE divide / sqrt, portable
  *          sin / cos / acos: bit-identical to the CPU oracle (oracle/pt_oracle.cpp, PORTABLE mode).  The parity anchor.
  *   FMA    the same source with FMA contraction (what nvcc does to the reference's kernels by default), IEEE
- *          divide / sqrt kept.
+ *          divide / sqrt kept; direction sampling with float-only sin / cos (<= 1.6 ulp, the accuracy class of the
+ *          sinf / cosf nvcc links; the diffuse lobe through square roots instead of acos).
  *   FAST   FMA + hardware reciprocal / rsqrt / sqrt / sin / cos, nested-FMA matrix products, float-only
  *          direction sampling.
  * FMA and FAST are held to the stated tolerance against the reference semantics (tests/test_gpu_arith.py):
