@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
     L.pt_scene_image_name.restype = C.c_char_p
     L.pt_build_bvh.argtypes = [C.POINTER(PtGeom), C.c_int, C.POINTER(PtBVHNode), C.c_int]
     L.pt_build_grid.argtypes = [C.POINTER(PtGeom), C.c_int, C.c_int, C.POINTER(PtGridInfo), C.POINTER(C.c_uint32), C.POINTER(PtGridRecord)]
+    if hasattr(L, "pt_selfcheck_ieee"):
+        L.pt_selfcheck_ieee.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
     if hasattr(L, "pt_traversal_boxes"):  # absent from older A/B builds of the library (tools/build_rev.sh)
         L.pt_traversal_boxes.argtypes = [C.POINTER(PtGeom), C.c_int, _fp, _fp]
     L.pt_build_transform.argtypes = [_fp, _fp, _fp, _fp]
@@ -236,6 +238,14 @@ class Scene:
         arr = (PtBVHNode * n)()
         lib().pt_build_bvh(self.desc.geoms, self.desc.num_geoms, arr, n)
         return arr
+
+
+def selfcheck_ieee(kind: int, first: int, count: int, seed: int = 0, arith: str = "exact") -> int:
+    """Mismatches between the guarded IEEE sqrt / reciprocal / quotient sequences and the compiler's expansions on the GPU
+    (pt_selfcheck_ieee)."""
+    n = C.c_uint64(0)
+    _check(lib().pt_selfcheck_ieee(ARITH[arith], kind, first, count, seed, C.byref(n)))
+    return int(n.value)
 
 
 def build_transform(trs: Sequence[float]):

@@ -992,6 +992,24 @@ extern "C" {
 const char* pt_last_error(void) { return g_err.c_str(); }
 int pt_library_has_ablations(void) { return kAblateBuild ? 1 : 0; }
 
+int pt_selfcheck_ieee(int arith, int kind, uint64_t first, uint64_t count, uint32_t seed, uint64_t* mismatches) {
+  const ptk::KernelApi* k = ptk::api_for(arith);
+  if (!k || kind < 0 || kind > 4 || !mismatches) return fail("pt_selfcheck_ieee: bad argument");
+  unsigned long long* d = nullptr;
+  HIP_OK(hipMalloc(&d, sizeof(*d)));
+  hipError_t e = hipMemset(d, 0, sizeof(*d));
+  if (e == hipSuccess) {
+    k->ieee_check(nullptr, kind, first, count, seed, d);
+    e = hipGetLastError();
+  }
+  unsigned long long h = 0;
+  if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail("pt_selfcheck_ieee: %s", hipGetErrorString(e));
+  *mismatches = h;
+  return 0;
+}
+
 // ---- scene -----------------------------------------------------------------
 struct PtScene {
   pt::Scene scene;

@@ -129,6 +129,9 @@ struct KernelApi {
   // otherwise exactly when staging them costs the bounce kernel no resident block per CU.
   int (*lds_table_limit)(const SceneTables& sc, int forced_bytes);
   int (*resident_blocks_per_cu)(KernelId id, const SceneTables& sc);
+  // Self-check of the guarded IEEE square root / reciprocal / quotient sequences (pt_kernels.hip namespace ieee) against the
+  // compiler's expansions on `count` operands starting at `first`; adds the number of mismatching results to *bad.
+  void (*ieee_check)(hipStream_t s, int kind, unsigned long long first, unsigned long long count, uint32_t seed, unsigned long long* bad);
 };
 const KernelApi* api_exact();
 const KernelApi* api_fma();

@@ -146,6 +146,100 @@ struct f3 {
   float x, y, z;
 };
 PT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+
+// Correctly rounded square root / reciprocal / quotient at about 60 % of the price of the compiler's expansions — same
+// results, bit for bit.  The compiler's expansions have to work for every input; three to seven of their 11 (divide) / 16
+// (sqrt) instructions — all of the half-rate kind — only serve inputs a path tracer does not see: v_div_scale / v_div_fmas /
+// v_div_fixup rescale operands whose quotient could leave the normal range and patch up zeros, infinities and NaNs; the
+// sqrt expansion pre-scales inputs below 2^-96, post-scales the result and restores 0 / inf / NaN with a class test.  When
+// EVERY active lane of the wave has operands inside a range where those instructions are the identity (one integer
+// compare per operand and a scalar branch), what remains is executed:
+//   sqrt   s = v_sqrt_f32(x); the neighbours s -/+ 1 ulp; residuals fma(-s', s, x); pick as the expansion does
+//   a / b  r = v_rcp_f32(b), one Newton step on r, q = a r, two residual corrections of q — the expansion's FMA chain, with a
+//          plain FMA where v_div_fmas (which is an FMA unless v_div_scale set VCC) stood
+// otherwise the wave runs the compiler's expansion.  Identity by construction inside the range (it is the same instruction
+// sequence); pt_selfcheck_ieee verifies it on the device against `__builtin_sqrtf`, `1.0f / x` and `a / b` for all 2^32 bit
+// patterns of x and for 2^33 operand pairs (tests/test_gpu_ieee_ops.py).  -DPT_IEEE_FAST=0 builds the plain expansions.
+#ifndef PT_IEEE_FAST
+#define PT_IEEE_FAST 1
+#endif
+namespace ieee {
+constexpr bool kGuarded = PT_IEEE_FAST != 0;
+PT_DEV bool every_lane(bool ok) { return __ballot(!ok) == 0ull; }
+// |v| in [2^-60, 2^60]: no v_div_scale case applies to a quotient of two such numbers, and the quotient is a normal number
+PT_DEV bool div_range(float v) { return ((__float_as_uint(v) & 0x7fffffffu) - 0x21800000u) < (0x5d800000u - 0x21800000u); }
+// x in [2^-96, 2^60]: at or above the expansion's pre-scaling threshold, finite; the root is in div_range
+PT_DEV bool sqrt_range(float x) { return (__float_as_uint(x) - 0x0f800000u) < (0x5d800000u - 0x0f800000u); }
+PT_DEV float sqrt_core(float x) {
+#pragma clang fp contract(off)
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
+  float r = rd <= 0.0f ? dn : s;
+  r = ru > 0.0f ? up : r;
+  return r;
+}
+PT_DEV float rcp_core(float b) {  // the refined reciprocal the quotients of one denominator share
+#pragma clang fp contract(off)
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+PT_DEV float quot_core(float a, float b, float r) {
+#pragma clang fp contract(off)
+  float q = a * r;
+  const float e2 = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(e2, r, q);
+  const float e3 = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(e3, r, q);
+}
+PT_DEV float sqrt(float x) {
+  if (kGuarded && every_lane(sqrt_range(x))) return sqrt_core(x);
+  return __builtin_sqrtf(x);
+}
+PT_DEV float div(float a, float b) {
+  if (kGuarded && every_lane(div_range(a) && div_range(b))) return quot_core(a, b, rcp_core(b));
+  return a / b;
+}
+PT_DEV float rcp(float b) {
+  if (kGuarded && every_lane(div_range(b))) return quot_core(1.0f, b, rcp_core(b));
+  return 1.0f / b;
+}
+// 1 / sqrt(x) as the reference forms it: two correctly rounded operations.  One range test covers both.
+PT_DEV float rcp_sqrt(float x) {
+  if (kGuarded && every_lane(sqrt_range(x))) {
+    const float s = sqrt_core(x);
+    return quot_core(1.0f, s, rcp_core(s));
+  }
+  return 1.0f / __builtin_sqrtf(x);
+}
+// (a1 / b, a2 / b) and (1/x, 1/y, 1/z): one range test, and the two quotients of one denominator share its reciprocal
+PT_DEV void div2(float a1, float a2, float b, float& q1, float& q2) {
+  if (kGuarded && every_lane(div_range(a1) && div_range(a2) && div_range(b))) {
+    const float r = rcp_core(b);
+    q1 = quot_core(a1, b, r), q2 = quot_core(a2, b, r);
+    return;
+  }
+  q1 = a1 / b, q2 = a2 / b;
+}
+// (a.x, a.y, a.z) / b.  (Zero numerators stay outside the guarded range: the correction chain turns -0 / b into +0 — found by the
+// self-check.)
+PT_DEV void div3(float& x, float& y, float& z, float b) {
+  if (kGuarded && every_lane(div_range(x) && div_range(y) && div_range(z) && div_range(b))) {
+    const float r = rcp_core(b);
+    x = quot_core(x, b, r), y = quot_core(y, b, r), z = quot_core(z, b, r);
+    return;
+  }
+  x = x / b, y = y / b, z = z / b;
+}
+PT_DEV void rcp3(float x, float y, float z, float& rx, float& ry, float& rz) {
+  if (kGuarded && every_lane(div_range(x) && div_range(y) && div_range(z))) {
+    rx = quot_core(1.0f, x, rcp_core(x)), ry = quot_core(1.0f, y, rcp_core(y)), rz = quot_core(1.0f, z, rcp_core(z));
+    return;
+  }
+  rx = 1.0f / x, ry = 1.0f / y, rz = 1.0f / z;
+}
+}  // namespace ieee
 // Exact a / n and a % n for 0 <= a < 2^30 and quotients below 2^15 (sample ids / tile pixels,
 // pixel index / image width): float estimate + one correction step either way, ~10 VALU instead of
 // the ~35 of a 32-bit integer division.  inv_n = 1.0f / n computed once per kernel.
@@ -919,7 +1013,7 @@ PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, i
     const float q = __builtin_fmaxf(mcolor.x, __builtin_fmaxf(mcolor.y, mcolor.z));
     if (rng.u01() > q) return bo;
     if (kFastDiv) s.c = scl(s.c, __builtin_amdgcn_rcpf(q));
-    else s.c = mk(s.c.x / q, s.c.y / q, s.c.z / q);
+    else ieee::div3(s.c.x, s.c.y, s.c.z, q);
   }
   const float reflectivity = m->reflective;
   bo.roughness = 1.0f - m->refractive;
@@ -2408,6 +2502,59 @@ void launch_collect(hipStream_t s, const BatchInfo& b, const ptd::Queues& qs, pt
   hipLaunchKernelGGL(k_collect, dim3(qs.Q), dim3(kCollectThreads), collect_lds_bytes(ret), s, b, qs, ret, image_rgb);
 }
 
+// Device self-check of the guarded IEEE sequences (namespace ieee) against the compiler's own expansions — pt_selfcheck_ieee.
+// kind 0 sqrt, 1 reciprocal, 2 1/sqrt: operand = the bit pattern first + i (a wave holds 64 consecutive patterns, so whole waves
+// are inside or outside the guarded range and both paths get exercised); kind 3 a / b, 4 the shared-reciprocal forms (div2, div3,
+// rcp3): operands from a hash of (seed, i), exponents drawn per WAVE either inside the guarded range (every lane: the short
+// sequence runs) or over everything incl. zeros, denormals, infinities and NaNs (the expansion runs), mantissas and signs per lane.
+PT_DEV bool same_float(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+PT_DEV uint32_t mix32(uint32_t x) {
+  x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+  return x;
+}
+__global__ void k_ieee_check(int kind, unsigned long long first, unsigned long long count, uint32_t seed, unsigned long long* __restrict__ bad) {
+#pragma clang fp contract(off)
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long mism = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const unsigned long long n = first + i;
+    if (kind <= 2) {
+      const float x = __uint_as_float((uint32_t)n);
+      const float got = kind == 0 ? ieee::sqrt(x) : kind == 1 ? ieee::rcp(x) : ieee::rcp_sqrt(x);
+      const float want = kind == 0 ? __builtin_sqrtf(x) : kind == 1 ? 1.0f / x : 1.0f / __builtin_sqrtf(x);
+      mism += !same_float(got, want);
+    } else {
+      const uint32_t wave_key = mix32((uint32_t)(n >> 6) ^ seed);
+      const bool inside = (wave_key & 7u) != 0u;  // 7 of 8 waves: every operand inside the guarded range
+      float v[4];
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t h = mix32((uint32_t)n * 4u + (uint32_t)j + mix32(seed + (uint32_t)(n >> 30)));
+        uint32_t e = inside ? 67u + (mix32(h ^ 0x9e3779b9u) % 120u) : (h >> 23) & 255u;  // biased exponent: [2^-60, 2^60) or anything
+        if (inside && (h & 0x1fu) == 0u) e = (h & 0x20u) ? 67u : 186u;                   // the edges of the range more often
+        v[j] = __uint_as_float((h & 0x807fffffu) | (e << 23));
+        if (!inside && (h & 0x300u) == 0u) v[j] = __uint_as_float(h & 0x80000000u);      // zeros among the unrestricted operands
+      }
+      if (kind == 3) {
+        mism += !same_float(ieee::div(v[0], v[1]), v[0] / v[1]);
+      } else {
+        float q1, q2, x = v[0], y = v[1], z = v[2], rx, ry, rz;
+        ieee::div2(v[0], v[1], v[3], q1, q2);
+        mism += !same_float(q1, v[0] / v[3]) + !same_float(q2, v[1] / v[3]);
+        if (n & 64u) x = __uint_as_float(__float_as_uint(x) & 0x80000000u);  // a signed zero numerator sends the wave through the expansion
+        const float x0 = x;
+        ieee::div3(x, y, z, v[3]);
+        mism += !same_float(x, x0 / v[3]) + !same_float(y, v[1] / v[3]) + !same_float(z, v[2] / v[3]);
+        ieee::rcp3(v[0], v[1], v[2], rx, ry, rz);
+        mism += !same_float(rx, 1.0f / v[0]) + !same_float(ry, 1.0f / v[1]) + !same_float(rz, 1.0f / v[2]);
+      }
+    }
+  }
+  if (mism) atomicAdd(bad, mism);
+}
+void launch_ieee_check(hipStream_t s, int kind, unsigned long long first, unsigned long long count, uint32_t seed, unsigned long long* bad) {
+  hipLaunchKernelGGL(k_ieee_check, dim3(4096), dim3(kBlock), 0, s, kind, first, count, seed, bad);
+}
+
 void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count,
                         unsigned long long* stats) {
   hipLaunchKernelGGL(k_count_stats, dim3(depth_count + 1), dim3(kBlock), 0, s, qs, cnt, depth_count, stats);
@@ -2437,7 +2584,7 @@ const KernelApi kApi = {
     "fast",
 #endif
     launch_generate, launch_primary, launch_bounce, launch_intersect, launch_shade, launch_collect, launch_count_stats,
-    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu};
+    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check};
 
 }  // namespace
 }  // namespace PT_NS

@@ -241,6 +241,13 @@ int pt_reset_stats(void);
 int pt_clear(void);
 const char* pt_last_error(void);
 int pt_library_has_ablations(void); /* 1: -DPT_ABLATE build (debug_flags bits 0-3 honoured) */
+/* Device self-check.  The exact and fma kernels (and depth 0 of every mode) take correctly rounded square roots,
+ * reciprocals and quotients from instruction sequences shorter than the compiler's general expansions whenever every
+ * lane's operands are in a range where the two are the same computation (csrc/pt_kernels.hip, namespace ieee).  This runs
+ * both side by side on the GPU and counts results that differ in any bit: kind 0 sqrt(x), 1 1/x, 2 1/sqrt(x) over the
+ * `count` bit patterns starting at `first` (2^32 patterns = every float); kind 3 a/b, 4 the shared-reciprocal forms over
+ * `count` pseudo-random operand sets derived from `seed` and the set's index first + i.  `arith` selects the kernel build. */
+int pt_selfcheck_ieee(int arith, int kind, uint64_t first, uint64_t count, uint32_t seed, uint64_t* mismatches);
 /* saveImage()'s per-pixel conversion (main.cpp:91-97 x mirror, image.cpp:26-30 clamp * 255 truncated) on the
  * device: pixel_count*3 bytes, row-major, x mirrored inside each row; the tile must consist of whole rows.
  * Reads back 3 B per pixel instead of 12. */
