@@ -2076,8 +2076,13 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
 #define PT_BIG_WAVES 5
 #endif
 constexpr int kBigWaves = PT_BIG_WAVES;
-template <bool GRID>
-__global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
+#ifndef PT_LITE_WAVES
+#define PT_LITE_WAVES 6
+#endif
+// SMALL (A/B experiment, debug_flags 128 on a scene whose tables fit LDS): the same one-group-at-a-time kernel with the scene
+// tables staged in LDS like k_bounce<true> — is the cornell bounce kernel better off with more waves and no pipelining?
+template <bool GRID, bool SMALL = false>
+__global__ __launch_bounds__(kBlock, SMALL ? PT_LITE_WAVES : kBigWaves) void k_bounce_big(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                                 const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
                                                                 ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
@@ -2090,14 +2095,23 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
   const ptd::Node* nodes = sc.nodes;
   const ptd::Geom* geoms = sc.geoms;
-  const int tbl = nb_top + nb_mats;
-  constexpr int kWaveBytes = GRID ? grid_wave_bytes<false>() : carry_bytes<false, 1>();
+  int tbl = nb_top + nb_mats;
+  if (SMALL) {
+    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
+    stage16(lds + tbl, sc.nodes, nb_nodes);
+    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
+    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
+    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
+    tbl += (nb_nodes + nb_geoms + 15) & ~15;
+  }
+  constexpr int kWaveBytes = GRID ? grid_wave_bytes<false>() : carry_bytes<SMALL, 1>();
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);
   iter_hash_fill(ihash, sc, b, depth);
   __syncthreads();
   const int wib = threadIdx.x >> 6;
-  Carry<false, 1> cy = carry_init<false, 1>(lds + tbl + wib * kWaveBytes);
-  CellRing cr{reinterpret_cast<uint32_t*>(lds + tbl + wib * kWaveBytes + carry_bytes<false, 1>()), 0, 0, nullptr};
+  Carry<SMALL, 1> cy = carry_init<SMALL, 1>(lds + tbl + wib * kWaveBytes);
+  CellRing cr{reinterpret_cast<uint32_t*>(lds + tbl + wib * kWaveBytes + carry_bytes<SMALL, 1>()), 0, 0, nullptr};
   if (GRID) cy.gix = cr.ent + kCellRing, cr.rinv = reinterpret_cast<float*>(cr.ent + kCellRing + kRing);
   cy.debug = b.debug;
   const int ntop = sc.num_top;
@@ -2117,10 +2131,10 @@ __global__ __launch_bounds__(kBlock, kBigWaves) void k_bounce_big(SceneTables sc
       f3 o, d;
       path_load_ray(in, at, o, d);
       cy.best[lane] = kNoHit;
-      if (GRID) grid_search<1>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
-      else carry_search<true, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
+      if constexpr (GRID) grid_search<1>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
+      else carry_search<!SMALL, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
     }
-    while (cy.count > 0) carry_chunk<false, 1, false, GRID>(cy, min(64, cy.count), lane, nodes, geoms);
+    while (cy.count > 0) carry_chunk<SMALL, 1, false, GRID>(cy, min(64, cy.count), lane, nodes, geoms);
     // shade: direction, colour and tag re-read from memory (planes 1 and 2; the search needed the registers)
     ShadeIO s;
     s.o = mk(0.f, 0.f, 0.f);
@@ -2375,6 +2389,11 @@ int big_lds_bytes(const SceneTables& sc) {
          iter_hash_entries(sc) * 4;
 }
 bool use_big(const SceneTables& sc) { return sc.big_kernel != 0 && !tables_in_lds(sc); }
+bool use_lite(const SceneTables& sc) { return sc.big_kernel != 0 && tables_in_lds(sc); }  // only ever on request (debug_flags 128)
+int lite_lds_bytes(const SceneTables& sc) {
+  return retire_lds_bytes(sc) + sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + round16(table_bytes(sc)) +
+         kWavesPerBlock * carry_bytes<true, 1>() + iter_hash_entries(sc) * 4;
+}
 int primary_grid_lds_bytes(const SceneTables& sc) {
   return retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<kD0>() + iter_hash_entries(sc) * 4;
 }
@@ -2424,6 +2443,7 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
     case kBounce:
       if (use_big(sc) && sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big<true>, kBlock, big_lds_bytes(sc));
       else if (use_big(sc)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big<false>, kBlock, big_lds_bytes(sc));
+      else if (use_lite(sc)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_bounce_big<false, true>), kBlock, lite_lds_bytes(sc));
       else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true, false>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
       break;
@@ -2473,6 +2493,7 @@ int launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInf
                   const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
   if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL(k_bounce_big<true>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
   else if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big<false>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
+  else if (use_lite(sc)) hipLaunchKernelGGL((k_bounce_big<false, true>), dim3(grid), dim3(kBlock), lite_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
   else if (tables_in_lds(sc) && levels > 1) {  // the LDS-table kernel, two bounces per pass (on request: measured slower)
     hipLaunchKernelGGL((k_bounce<true, true>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()) + iter_hash_entries(sc) * 4, s, sc, b, depth, 2, qs, cnt_in, cnt_mid, cnt_out, in, out, ret);
     return 2;

@@ -2,7 +2,13 @@
 //  mode 0: 6 dword plane loads + 8 dword plane stores per lane (SoA of scalars, current layout)
 //  mode 1: float3 + float3 loads, float4 + float4 stores (SoA of small vectors)
 //  mode 2: float4 + float2 loads, float4 + float4 stores
-// All move 56 B per element.  Reports TB/s for N elements.
+//  modes 0-2 move 56 B per element.
+//  mode 3 (round 3): the fused bounce kernel's own record layout and traffic — three planes of 16 + 16 + 8 B read per path,
+//          and per path either the same three planes written (a survivor, 71 % of the lanes — cornell's ray-weighted average over
+//          depths 1-7 — contiguous per wave after a ballot / prefix compaction, like the kernel's queue append) or one 16-B record
+//          (a retired sample): 40 B read + 0.71 * 40 + 0.29 * 16 = 33 B written per path; nothing else is done with the data.  What a kernel with
+//          k_bounce's bytes and access shape can reach on this machine when it does no work at all.
+// Reports TB/s for N elements.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -36,6 +42,76 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ in, float* __
     }
   }
 }
+struct W4 { float x, y, z, w; };
+// V 0: as the kernel does it — Q = 256 queues own n / Q consecutive paths each, the waves w, w + Q, ... of the grid serve queue w % Q
+//      (all on one XCD: blockIdx steps by 64), take its 64-path groups round-robin, append the survivors to the queue's output
+//      region at a base reserved with one returning atomic per wave and group, and the retired records to a segment of their own;
+//   1: the same with the reservation taken from a wave-private counter (no atomic): output runs of one wave stay contiguous,
+//      runs of different waves leave gaps;  2: no retired records;  3: every path survives (plain copy in this work distribution)
+template <int V>
+__global__ __launch_bounds__(256) void k3(const W4* __restrict__ in, const float2* __restrict__ in2, W4* __restrict__ out, float2* __restrict__ out2,
+                                          W4* __restrict__ ret, int* __restrict__ cnt, long n) {
+  const int Q = 256;
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), W = gridDim.x * 4;
+  const int q = wave % Q, r = wave / Q, wq = W / Q;
+  const long cap = n / Q, qbase = (long)q * cap;  // n is a multiple of 64 * Q
+  long mine = 0, dead_at = 0;
+  for (long j = r; j * 64 < cap; j += wq) {
+    const long at = qbase + j * 64 + lane;
+    const W4 a = in[at], b = in[n + at];
+    const float2 c = in2[at];
+    const bool live = V == 3 || ((__float_as_uint(a.x) ^ (uint32_t)at * 2654435761u) % 100u) < 71u;
+    const unsigned long long m = __ballot(live);
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    long base;
+    if (V == 0) {
+      int bq = 0;
+      if (lane == 0) bq = atomicAdd(&cnt[q * 16], __popcll(m));
+      base = qbase + __builtin_amdgcn_readfirstlane(bq);
+    } else {
+      base = qbase + (long)r * (cap / wq) + mine;  // the wave's own slice of the queue's region
+      mine += __popcll(m);
+    }
+    if (live) {
+      const long o = base + rank;
+      out[o] = W4{a.x + 1, a.y, a.z, b.x}, out[n + o] = W4{b.y, b.z, b.w, c.x}, out2[o] = make_float2(c.y, a.w);
+    } else if (V < 2) {
+      ret[qbase + (long)r * (cap / wq) + dead_at + (lane - rank)] = W4{a.x, b.y, c.x, a.w};
+    }
+    dead_at += 64 - __popcll(m);
+  }
+}
+template <int V> int run3(long n, int bpc) {
+  W4 *in, *out, *ret; float2 *in2, *out2; int* cnt;
+  CK(hipMalloc(&in, n * 32 + 64)); CK(hipMalloc(&in2, n * 8 + 64)); CK(hipMalloc(&out, n * 32 + 64)); CK(hipMalloc(&out2, n * 8 + 64));
+  CK(hipMalloc(&ret, n * 16 + 1024)); CK(hipMalloc(&cnt, 16384));
+  n = n / (64 * 256) * (64 * 256);
+  CK(hipMemset(in, 1, n * 32)); CK(hipMemset(in2, 1, n * 8)); CK(hipMemset(cnt, 0, 16384));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int grid = 256 * bpc;
+  for (int w = 0; w < 2; ++w) {
+    CK(hipMemsetAsync(cnt, 0, 16384));
+    hipLaunchKernelGGL(k3<V>, dim3(grid), dim3(256), 0, 0, in, in2, out, out2, ret, cnt, n);
+  }
+  const int reps = 10;
+  float ms = 0;
+  for (int r = 0; r < reps; ++r) {
+    float one;
+    CK(hipMemsetAsync(cnt, 0, 16384));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k3<V>, dim3(grid), dim3(256), 0, 0, in, in2, out, out2, ret, cnt, n);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&one, e0, e1));
+    ms += one;
+  }
+  const double bytes = V == 3 ? 80.0 : 40.0 + 0.71 * 40.0 + (V == 2 ? 0.0 : 0.29 * 16.0);
+  const char* names[4] = {"k_bounce traffic, no work", "  same, wave-private output slices", "  same, no retired records", "  every path survives (copy)"};
+  printf("%-34s n=%.1fM blocks/CU=%d: %.1f us/launch, %.2f TB/s (%.1f B/path)\n", names[V], n / 1048576.0, bpc, ms * 1e3 / reps,
+         bytes * n * reps / (ms * 1e-3) / 1e12, bytes);
+  CK(hipFree(in)); CK(hipFree(in2)); CK(hipFree(out)); CK(hipFree(out2)); CK(hipFree(ret)); CK(hipFree(cnt));
+  return 0;
+}
 template <int MODE> int run(const char* name, long n, int bpc) {
   float *in, *out;
   CK(hipMalloc(&in, n * 6 * 4 + 64)); CK(hipMalloc(&out, n * 8 * 4 + 64));
@@ -53,6 +129,12 @@ template <int MODE> int run(const char* name, long n, int bpc) {
   return 0;
 }
 int main() {
+  for (long n : {24100000L, 11630000L}) for (int bpc : {4, 8}) {
+    if (run3<0>(n, bpc)) return 1;
+    if (run3<1>(n, bpc)) return 1;
+    if (run3<2>(n, bpc)) return 1;
+    if (run3<3>(n, bpc)) return 1;
+  }
   for (long n : {12L << 20, 3L << 20}) for (int bpc : {5, 8}) {
     if (run<0>("SoA dword (6 ld + 8 st)", n, bpc)) return 1;
     if (run<1>("float3,float3 -> float4,float4", n, bpc)) return 1;
