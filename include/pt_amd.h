@@ -98,7 +98,8 @@ typedef struct PtOptions {
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
   int32_t debug_flags;      /* A-B switches with UNCHANGED results: 16 no closer-hit cull in the subtree scans, 32 no
                                near-first subtree order, 64 / 128 force the pipelined / the high-occupancy depth >= 1
-                               kernel for scenes whose tables are not in LDS (default: by BVH size), 256 / 512 force /
+                               kernel for scenes whose tables are not in LDS (default: by BVH size; 128 on a scene whose tables
+                               ARE in LDS runs the one-group-at-a-time kernel with LDS tables — an occupancy experiment: same time), 256 / 512 force /
                                forbid the uniform-grid walk of the fused kernels (default: for large scenes, whichever of
                                the BVH scan and up to three grid resolutions renders a few iterations fastest at pt_init), 1024 two bounces per pass in the fused
                                bounce kernel of small scenes (the survivors of every other depth stay in registers instead of

@@ -175,6 +175,8 @@ def test_striped_tiles_compose(scene_dir):
     ((320, 200), dict(num_queues=32, unfused_primary=True, iters_per_batch=5)),
     ((320, 200), dict(debug_flags=1024)),                     # two bounces per pass: depths 1+2, 3+4, 5+6, 7
     ((320, 200), dict(debug_flags=1024, iters_per_batch=7, num_queues=16)),
+    ((320, 200), dict(debug_flags=128)),                      # the one-group-at-a-time kernel with LDS tables (occupancy experiment)
+    ((320, 201), dict(debug_flags=128, num_queues=32, iters_per_batch=6)),
 ])
 def test_retirement_records_and_collect_layouts(scene_dir, res, kw):
     """The retirement path (ptd::RetireBuf: queues own fixed pixel chunks, wave-private record segments, k_collect's LDS
