@@ -50,8 +50,7 @@ struct W4 { float x, y, z, w; };
 //      runs of different waves leave gaps;  2: no retired records;  3: every path survives (plain copy in this work distribution)
 template <int V>
 __global__ __launch_bounds__(256) void k3(const W4* __restrict__ in, const float2* __restrict__ in2, W4* __restrict__ out, float2* __restrict__ out2,
-                                          W4* __restrict__ ret, int* __restrict__ cnt, long n) {
-  const int Q = 256;
+                                          W4* __restrict__ ret, int* __restrict__ cnt, long n, int Q) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), W = gridDim.x * 4;
   const int q = wave % Q, r = wave / Q, wq = W / Q;
@@ -82,32 +81,32 @@ __global__ __launch_bounds__(256) void k3(const W4* __restrict__ in, const float
     dead_at += 64 - __popcll(m);
   }
 }
-template <int V> int run3(long n, int bpc) {
+template <int V> int run3(long n, int bpc, int Q = 256) {
   W4 *in, *out, *ret; float2 *in2, *out2; int* cnt;
   CK(hipMalloc(&in, n * 32 + 64)); CK(hipMalloc(&in2, n * 8 + 64)); CK(hipMalloc(&out, n * 32 + 64)); CK(hipMalloc(&out2, n * 8 + 64));
-  CK(hipMalloc(&ret, n * 16 + 1024)); CK(hipMalloc(&cnt, 16384));
-  n = n / (64 * 256) * (64 * 256);
-  CK(hipMemset(in, 1, n * 32)); CK(hipMemset(in2, 1, n * 8)); CK(hipMemset(cnt, 0, 16384));
+  CK(hipMalloc(&ret, n * 16 + 1024)); CK(hipMalloc(&cnt, 65536));
+  n = n / (64 * 1024) * (64 * 1024);
+  CK(hipMemset(in, 1, n * 32)); CK(hipMemset(in2, 1, n * 8)); CK(hipMemset(cnt, 0, 65536));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int grid = 256 * bpc;
   for (int w = 0; w < 2; ++w) {
-    CK(hipMemsetAsync(cnt, 0, 16384));
-    hipLaunchKernelGGL(k3<V>, dim3(grid), dim3(256), 0, 0, in, in2, out, out2, ret, cnt, n);
+    CK(hipMemsetAsync(cnt, 0, 65536));
+    hipLaunchKernelGGL(k3<V>, dim3(grid), dim3(256), 0, 0, in, in2, out, out2, ret, cnt, n, Q);
   }
   const int reps = 10;
   float ms = 0;
   for (int r = 0; r < reps; ++r) {
     float one;
-    CK(hipMemsetAsync(cnt, 0, 16384));
+    CK(hipMemsetAsync(cnt, 0, 65536));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k3<V>, dim3(grid), dim3(256), 0, 0, in, in2, out, out2, ret, cnt, n);
+    hipLaunchKernelGGL(k3<V>, dim3(grid), dim3(256), 0, 0, in, in2, out, out2, ret, cnt, n, Q);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&one, e0, e1));
     ms += one;
   }
   const double bytes = V == 3 ? 80.0 : 40.0 + 0.71 * 40.0 + (V == 2 ? 0.0 : 0.29 * 16.0);
   const char* names[4] = {"k_bounce traffic, no work", "  same, wave-private output slices", "  same, no retired records", "  every path survives (copy)"};
-  printf("%-34s n=%.1fM blocks/CU=%d: %.1f us/launch, %.2f TB/s (%.1f B/path)\n", names[V], n / 1048576.0, bpc, ms * 1e3 / reps,
+  printf("%-34s n=%.1fM blocks/CU=%d Q=%d: %.1f us/launch, %.2f TB/s (%.1f B/path)\n", names[V], n / 1048576.0, bpc, Q, ms * 1e3 / reps,
          bytes * n * reps / (ms * 1e-3) / 1e12, bytes);
   CK(hipFree(in)); CK(hipFree(in2)); CK(hipFree(out)); CK(hipFree(out2)); CK(hipFree(ret)); CK(hipFree(cnt));
   return 0;
@@ -129,6 +128,10 @@ template <int MODE> int run(const char* name, long n, int bpc) {
   return 0;
 }
 int main() {
+  for (int Q : {16, 64, 256, 1024}) {  // number of queues = concurrent input / output streams
+    if (run3<0>(11630000L, 4, Q)) return 1;
+    if (run3<3>(11630000L, 4, Q)) return 1;
+  }
   for (long n : {24100000L, 11630000L}) for (int bpc : {4, 8}) {
     if (run3<0>(n, bpc)) return 1;
     if (run3<1>(n, bpc)) return 1;
