@@ -23,6 +23,9 @@ Extra objects on the JSON line:
                  timed region) vs 8 TB/s; `traffic` = HBM bytes per launch from the committed PMC passes
                  (profiles/dominant_kernel_traffic.json holds bytes PER RAY for this arithmetic mode) scaled by
                  this run's rays per launch.
+  roofline.traffic_floor  measured in the same call: a kernel that only moves k_bounce's bytes in k_bounce's work distribution
+                 (build/tools/ubench_stream --floor, tools/ubench_stream.hip) on this run's rays per launch — what this traffic can
+                 reach on this box with no computation at all, in us and as a fraction of the 8 TB/s peak in roofline units
   roofline_valu  the kernel's instruction-issue ceiling: its dynamic VALU mix (committed PMC passes, SQ_INSTS_VALU_*
                  per 64-ray group) priced at the MEASURED issue rates of tools/ubench_valu.hip (profiles/
                  r03_ubench_valu.txt: f32 add / mul / fma 2.3-2.45 SIMD cycles per wave64 instruction, selects /
@@ -289,10 +292,33 @@ def main() -> None:
             modes[m] = {"value": out["value"] if m == args.arith else sv, "steps": args.steps if m == args.arith else msteps,
                         "steady_value": sv, "steady_steps": msteps,
                         "k_bounce_us": round(s1.intersect_ms * 1e3 / max(1, s1.intersect_launches), 3),
+                        "rays_per_launch": round(u1 / max(1, s1.intersect_launches), 1),
                         "hbm_frac": round(a1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None,
                         "hbm_frac_56B": round(ISECT_BYTES_PER_RAY * u1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None}
             rr.free()
         out["modes"] = modes
+        # ---- the traffic floor of the dominant kernel, measured in this call: a kernel that does nothing but k_bounce's
+        # memory traffic in k_bounce's work distribution (tools/ubench_stream.hip --floor), on this run's rays per launch
+        if roofline and st.bounces_fused:
+            exe = os.path.join(ROOT, "build", "tools", "ubench_stream")
+            floor = None
+            if os.path.exists(exe):
+                try:
+                    import subprocess
+                    # compared with the steady leg of the headline mode (same process, full batches): its rays per launch
+                    leg = modes[args.arith]
+                    line = subprocess.run([exe, "--floor", str(int(leg["rays_per_launch"]))], capture_output=True, text=True, timeout=120).stdout.strip().split("\n")[-1]
+                    f = json.loads(line)
+                    floor_us = float(f["us_per_launch"]) * leg["rays_per_launch"] / f["paths"]  # the benchmark rounds the path count down
+                    alg = roofline["algorithmic_bytes_per_launch"] / roofline["rays_per_launch"] * leg["rays_per_launch"]
+                    floor = {"kernel": "no-work kernel: 3-plane records in, 71 % compacted survivors + 29 % 16-byte records out, 256 queues, atomic append",
+                             "rays_per_launch": leg["rays_per_launch"], "us_per_launch": round(floor_us, 2), "tb_per_s": f["tb_per_s"],
+                             "frac_of_peak_in_roofline_units": round(alg / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                             "k_bounce_steady_us": leg["k_bounce_us"], "k_bounce_steady_frac": leg["hbm_frac"],
+                             "floor_over_k_bounce": round(floor_us / leg["k_bounce_us"], 4) if leg["k_bounce_us"] else None}
+                except Exception as e:  # a missing or failing helper must not break the bench line
+                    floor = {"error": str(e)[:200]}
+            roofline["traffic_floor"] = floor
         # the reference builds WITHOUT -use_fast_math (CMakeLists.txt:26-30): FMA contraction, IEEE divide / sqrt — that is
         # the `fma` mode; quote it beside the headline
         out["value_fma"] = modes["fma"]["steady_value"]

@@ -11,6 +11,8 @@
 // Reports TB/s for N elements.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 struct __attribute__((packed, aligned(4))) f3 { float x, y, z; };
 template <int MODE>
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void k3(const W4* __restrict__ in, const float
     dead_at += 64 - __popcll(m);
   }
 }
-template <int V> int run3(long n, int bpc, int Q = 256) {
+template <int V> int run3(long n, int bpc, int Q = 256, bool json = false) {
   W4 *in, *out, *ret; float2 *in2, *out2; int* cnt;
   CK(hipMalloc(&in, n * 32 + 64)); CK(hipMalloc(&in2, n * 8 + 64)); CK(hipMalloc(&out, n * 32 + 64)); CK(hipMalloc(&out2, n * 8 + 64));
   CK(hipMalloc(&ret, n * 16 + 1024)); CK(hipMalloc(&cnt, 65536));
@@ -106,8 +108,12 @@ template <int V> int run3(long n, int bpc, int Q = 256) {
   }
   const double bytes = V == 3 ? 80.0 : 40.0 + 0.71 * 40.0 + (V == 2 ? 0.0 : 0.29 * 16.0);
   const char* names[4] = {"k_bounce traffic, no work", "  same, wave-private output slices", "  same, no retired records", "  every path survives (copy)"};
-  printf("%-34s n=%.1fM blocks/CU=%d Q=%d: %.1f us/launch, %.2f TB/s (%.1f B/path)\n", names[V], n / 1048576.0, bpc, Q, ms * 1e3 / reps,
-         bytes * n * reps / (ms * 1e-3) / 1e12, bytes);
+  if (json)
+    printf("{\"paths\": %ld, \"us_per_launch\": %.2f, \"bytes_per_path\": %.1f, \"tb_per_s\": %.3f, \"queues\": %d, \"blocks_per_cu\": %d}\n", n, ms * 1e3 / reps, bytes,
+           bytes * n * reps / (ms * 1e-3) / 1e12, Q, bpc);
+  else
+    printf("%-34s n=%.1fM blocks/CU=%d Q=%d: %.1f us/launch, %.2f TB/s (%.1f B/path)\n", names[V], n / 1048576.0, bpc, Q, ms * 1e3 / reps,
+           bytes * n * reps / (ms * 1e-3) / 1e12, bytes);
   CK(hipFree(in)); CK(hipFree(in2)); CK(hipFree(out)); CK(hipFree(out2)); CK(hipFree(ret)); CK(hipFree(cnt));
   return 0;
 }
@@ -127,7 +133,9 @@ template <int MODE> int run(const char* name, long n, int bpc) {
   CK(hipFree(in)); CK(hipFree(out));
   return 0;
 }
-int main() {
+int main(int argc, char** argv) {
+  // --floor N: only the no-work kernel with k_bounce's traffic on N paths (256 queues, 4 blocks per CU), one JSON line (bench.py)
+  if (argc >= 3 && std::string(argv[1]) == "--floor") return run3<0>(atol(argv[2]), 4, 256, true);
   for (int Q : {16, 64, 256, 1024}) {  // number of queues = concurrent input / output streams
     if (run3<0>(11630000L, 4, Q)) return 1;
     if (run3<3>(11630000L, 4, Q)) return 1;
