@@ -120,7 +120,7 @@ struct PtContext {
   bool fuse_primary = true, fuse_bounces = true;
   bool aa_jitter = false;
   bool has_triangles = false;  // SceneTables::has_triangles
-  int grid_primary = 0, grid_bounce = 0;
+  int grid_primary = 0, grid_bounce = 0, grid_bounce_all = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
   ptd::RetireBuf ret{};  // retirement records + fill levels (pt_device.h)
@@ -525,6 +525,7 @@ ptk::SceneTables tables(const Ctx& g) {
   t.lds_table_bytes = g.lds_table_bytes;
   t.max_batch_iters = g.K;
   t.has_triangles = g.has_triangles ? 1 : 0;
+  t.trace_depth = g.depth;
   // k_bounce_big from kBigKernelNodes nodes on; debug_flags 64 / 128 force k_bounce<false> / k_bounce_big (A/B, same results)
   t.big_kernel = (g.debug_flags & 64) ? 0 : ((g.debug_flags & 128) ? 1 : (g.num_nodes >= kBigKernelNodes ? 1 : 0));
   // the grid walk lives in the big kernel; debug_flags 256 builds and uses it for any scene, 512 never (A/B, same results)
@@ -591,7 +592,22 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   // slower than one per pass, DESIGN.md section 5, so not the default): the input alternates between the two path buffers
   // per LAUNCH, not per depth
   int src = d0 & 1;
-  for (int d = d0; d < g.depth;) {
+  // debug_flags 4096 (experiment): all depths >= 1 in ONE launch of k_bounce_all — persistent lanes with their own depth, no
+  // path state through HBM after depth 0 (small-scene kernels only)
+  const bool all_depths = (g.debug_flags & 4096) && g.fuse_primary && g.fuse_bounces && g.grid_bounce_all > 0 && !sc.big_kernel && g.depth > 1 && g.depth <= 9;  // (the kernel counts rays per depth for depths 1..8)
+  if (all_depths) {
+    EventPair ev{};
+    if (g.time_kernels) {
+      if (get_events(g, &ev)) return -1;
+      HIP_OK(hipEventRecord(ev.a, g.stream));
+    }
+    k.bounce_all(g.stream, g.grid_bounce_all, sc, b, queues_for(g, g.grid_bounce_all), g.d_cnt, g.buf[1], g.ret);
+    if (g.time_kernels) {
+      HIP_OK(hipEventRecord(ev.b, g.stream));
+      g.pending_isect.push_back(ev);
+    }
+  }
+  for (int d = d0; d < g.depth && !all_depths;) {
     const int32_t* cin = g.d_cnt + per_depth * d;
     int32_t* cmid = g.d_cnt + per_depth * (d + 1);
     EventPair ev{};
@@ -650,6 +666,7 @@ void plan_launch(Ctx& g) {
   g.grid_shade = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kShade, t));
   g.grid_primary = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
   g.grid_bounce = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounce, t));
+  g.grid_bounce_all = (g.debug_flags & 4096) ? g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounceAll, t)) : 0;
 }
 
 // Make candidate i the grid the kernels walk.

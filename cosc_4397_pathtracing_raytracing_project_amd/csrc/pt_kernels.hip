@@ -2065,6 +2065,202 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   retire_end(rt, ret, b, q, r, lane);
 }
 
+// ── ALL depths >= 1 in one launch (experiment, debug_flags 4096; LDS-table scenes) ────────────────────────────────────────
+// k_bounce runs at 83 % of the speed of a kernel that only moves its bytes, so the way up is fewer
+// bytes: here a path never goes back to HBM.  A wave keeps two persistent groups of 64 lanes; a lane carries its ray, its
+// throughput, its sample id and ITS OWN depth.  When a path dies the lane writes the 16-byte retirement record and takes the
+// next depth-1 ray of the wave's slice of its queue (k_primary's output); survivors stay where they are, at depth + 1.  The
+// search, the candidate ring and the primitive-test chunks are per ray already (candidates carry their owner lane and group),
+// the RNG is keyed per lane by (iteration, pixel, depth), the retirement records by iteration: nothing else changes, and
+// neither can the results.  Traffic per bounce ray: the 40-byte read and the 16-byte record of its PATH, once.
+//   * refill without a stall: the next 64 rays' (o, d) wait in an LDS ring (1.5 KB per wave); a dead lane of rank r takes
+//     slot head + r, its colour / sample id come straight from memory (first needed two searches later), and the ring is
+//     topped up with loads issued now and written to LDS at the NEXT refill, one search later.
+//   * the group searched in an iteration is shaded in the next one, after the other group's search has pushed its last
+//     candidates through the ring (as in k_bounce), then refilled.
+template <bool TABLES_IN_LDS>
+__global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
+                                                                     ptd::PathBuf in, ptd::RetireBuf ret) {
+  extern __shared__ float4 lds_raw[];
+  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);
+  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
+  stage16(lds, sc.top, nb_top);
+  stage16(lds + nb_top, sc.mats, nb_mats);
+  const float4* top = reinterpret_cast<const float4*>(lds);
+  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
+  const ptd::Node* nodes = sc.nodes;
+  const ptd::Geom* geoms = sc.geoms;
+  int tbl = nb_top + nb_mats;
+  if (TABLES_IN_LDS) {
+    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
+    stage16(lds + tbl, sc.nodes, nb_nodes);
+    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
+    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
+    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
+    tbl += nb_nodes + nb_geoms;
+  }
+  constexpr int kFifoBytes = 6 * 64 * 4;
+  const int wave_bytes = carry_bytes<TABLES_IN_LDS>() + kFifoBytes;
+  // iteration-hash rows of the depths 1 .. trace_depth - 1 behind the per-wave blocks
+  const int he = iter_hash_entries(sc);
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * wave_bytes);
+  for (int d = 1; d < b.trace_depth; ++d) iter_hash_fill(ihash + (d - 1) * he, sc, b, d);
+  __syncthreads();
+  const int wib = threadIdx.x >> 6;
+  Carry<TABLES_IN_LDS> cy = carry_init<TABLES_IN_LDS>(lds + tbl + wib * wave_bytes);
+  float* fifo = reinterpret_cast<float*>(lds + tbl + wib * wave_bytes + carry_bytes<TABLES_IN_LDS>());  // [6][64]: o.xyz, d.xyz of the next 64 rays
+  cy.debug = b.debug;
+  const int ntop = sc.num_top;
+  const int wave = blockIdx.x * kWavesPerBlock + wib;
+  const int lane = lane_id();
+  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
+  const size_t per_depth = (size_t)qs.Q * qs.cnt_stride;
+  const int n_q = cnt[per_depth * 1 + (size_t)q * qs.cnt_stride];  // depth-1 rays of the queue (k_primary's survivors)
+  const int64_t qbase = (int64_t)q * qs.cap;
+  // the wave's slice of the queue's input
+  const int per = (n_q + wq - 1) / wq;
+  const int lo = min(r * per, n_q), hi = min(lo + per, n_q);
+  int given = lo;   // rays handed to lanes so far: [lo, given)
+  int head = 0;     // FIFO slot of ray `given`
+  struct Group {
+    f3 o, d, c;
+    int slot, depth;
+    bool valid, pending;
+    int mark;
+  };
+  Group G[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    G[p].o = G[p].d = G[p].c = mk(0.f, 0.f, 0.f);
+    G[p].slot = 0, G[p].depth = 1, G[p].valid = false, G[p].pending = false, G[p].mark = 0;
+  }
+  // FIFO: rays given .. given + 63 (clamped into the slice; slots beyond `hi` are never consumed)
+  auto load_od = [&](int i, f3& o, f3& d) {
+    const int64_t at = qbase + min(max(i, lo), max(hi - 1, lo));
+    const ptd::Word4 w0 = in.r[at], w1 = in.r[in.stride + at];
+    o = mk(w0.x, w0.y, w0.z), d = mk(w0.w, w1.x, w1.y);
+  };
+  f3 so, sd;  // top-up staging (registers): the rays that replace the slots consumed by the previous refill
+  int staged = 0, staged_at = 0;  // their count and first FIFO slot
+  if (hi > lo) {
+    load_od(lo + lane, so, sd);
+    fifo[0 * 64 + lane] = so.x, fifo[1 * 64 + lane] = so.y, fifo[2 * 64 + lane] = so.z;
+    fifo[3 * 64 + lane] = sd.x, fifo[4 * 64 + lane] = sd.y, fifo[5 * 64 + lane] = sd.z;
+  }
+  int streamed = min(lo + 64, hi);  // rays whose (o, d) are in the FIFO or staged: [given, streamed)
+  unsigned int traced[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rays searched per depth (statistics), depths 1..8 -> [0..7]; deeper ones in [7]
+  auto refill = [&](Group& g) {
+    // 1. last refill's top-up has landed: into the FIFO
+    if (staged > 0) {
+      if (lane < staged) {
+        const int sl = (staged_at + lane) & 63;
+        fifo[0 * 64 + sl] = so.x, fifo[1 * 64 + sl] = so.y, fifo[2 * 64 + sl] = so.z;
+        fifo[3 * 64 + sl] = sd.x, fifo[4 * 64 + sl] = sd.y, fifo[5 * 64 + sl] = sd.z;
+      }
+      staged = 0;
+    }
+    // 2. dead lanes take the next rays
+    const unsigned long long dead = __ballot(!g.valid);
+    const int want = __popcll(dead);
+    const int n = min(want, streamed - given);  // only rays whose (o, d) are already in the FIFO
+    if (n > 0) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0));
+      const bool take = !g.valid && rank < n;
+      if (take) {
+        const int sl = (head + rank) & 63;
+        g.o = mk(fifo[0 * 64 + sl], fifo[1 * 64 + sl], fifo[2 * 64 + sl]);
+        g.d = mk(fifo[3 * 64 + sl], fifo[4 * 64 + sl], fifo[5 * 64 + sl]);
+        const int64_t at = qbase + given + rank;
+        const ptd::Word4 w1 = in.r[in.stride + at];
+        PathTag tg;
+        float cz;
+        plane2_load(in, at, cz, tg);
+        g.c = mk(w1.z, w1.w, cz);
+        g.slot = tg.slot;
+        g.depth = 1;
+        g.valid = true;
+      }
+      // 3. top up the consumed slots: loads now, LDS write at the next refill
+      if (streamed < hi) {
+        staged = min(n, hi - streamed);
+        staged_at = head;
+        if (lane < staged) load_od(streamed + lane, so, sd);
+        streamed += staged;
+      }
+      given += n;
+      head = (head + n) & 63;
+    }
+  };
+  refill(G[0]);
+  refill(G[1]);
+  auto search = [&](Group& g, int par) {
+    const unsigned long long v = __ballot(g.valid);
+    g.pending = v != 0ull;
+    if (!g.pending) return;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) traced[d] += (unsigned int)__popcll(__ballot(g.valid && (d < 7 ? g.depth == d + 1 : g.depth >= 8)));
+    cy.best[par * 64 + lane] = kNoHit;
+    carry_search<!TABLES_IN_LDS, 2>(cy, top, ntop, nodes, geoms, g.o, g.d, g.valid, lane, par, sc.cull_margin, sc.top_xor);
+    g.mark = cy.appended;
+  };
+  auto shade = [&](Group& g, int par) {
+    if (!g.pending) return;
+    carry_drain_to(cy, g.mark, lane, nodes, geoms);
+    const unsigned long long best = cy.best[par * 64 + lane];
+    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+    ShadeIO s;
+    s.o = mk(0.f, 0.f, 0.f);
+    s.d = g.d;
+    s.c = g.c;
+    s.alive = false;
+    Bounce bo;
+    bo.kind = 0;
+    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+    PathTag tag;
+    tag.slot = g.slot, tag.phash = 0u, tag.k = 0;
+    int k, pl;
+    sample_of(tag, b, k, pl);
+    if (g.valid) {
+      float ht = -1.0f;
+      int hmat = 0;
+      if (hit) {
+        ht = __uint_as_float((uint32_t)(best >> 32));
+        hmat = geoms[nodes[(uint32_t)best].geom].material;
+        const float* rr = cy.rec + par * 6 * 64 + lane;
+        hn = mk(rr[0 * 64], rr[1 * 64], rr[2 * 64]);
+        hp = mk(rr[3 * 64], rr[4 * 64], rr[5 * 64]);
+      }
+      const uint32_t ph = utilhash((uint32_t)global_pixel(b, pl));
+      const uint32_t ih = he > 0 ? ihash[(g.depth - 1) * he + k] : iter_hash(b.iter_first + k, g.depth);
+      bo = shade_decide(mats, b.trace_depth, g.depth, ih ^ ph, ht, hmat, s);
+    }
+    const bool alive = g.valid && s.alive, dead = g.valid && !s.alive;
+    const int rpos = retire_reserve(rt, dead, k);
+    retire_store(rt, dead, k, rpos, pl, s.c);
+    if (alive) shade_bounce(bo, hn, hp, s);
+    g.o = s.o, g.d = s.d, g.c = s.c;
+    g.depth += 1;
+    g.valid = alive;
+    g.pending = false;
+    refill(g);
+  };
+  while (true) {
+    search(G[0], 0);
+    shade(G[1], 1);
+    search(G[1], 1);
+    shade(G[0], 0);
+    if (!__ballot(G[0].valid || G[1].valid)) break;  // every path of the slice has retired (a refill would have revived a lane)
+  }
+  // statistics: rays traced per depth >= 2 (row 1 holds the queue's input count already)
+  if (lane == 0)
+    for (int d = 2; d < b.trace_depth && d <= 8; ++d)
+      if (traced[d - 1]) atomicAdd(&cnt[per_depth * d + (size_t)q * qs.cnt_stride], (int)traced[d - 1]);
+  retire_end(rt, ret, b, q, r, lane);
+}
+
 // ── depth >= 1 for scenes with subtrees below the top list (thousands of primitives) ────────────────
 // Same stages as k_bounce<false>, one group at a time per wave: load, search (ring + chunks as before), drain, shade, emit,
 // with what is needed only at the end (throughput colour, slot) re-read from memory.  k_bounce's pipelining (next group
@@ -2382,6 +2578,10 @@ int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool prima
 }
 int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
+int all_lds_bytes(const SceneTables& sc) {  // one iteration-hash row is in fused_lds_bytes already
+  return fused_lds_bytes(sc, tables_in_lds(sc), (tables_in_lds(sc) ? carry_bytes<true>() : carry_bytes<false>()) + 6 * 64 * 4) +
+         iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 2);
+}
 int big_lds_bytes(const SceneTables& sc) {
   if (sc.use_grid)
     return retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<false>() + iter_hash_entries(sc) * 4;
@@ -2447,6 +2647,10 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true, false>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
       break;
+    case kBounceAll:
+      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_all<true>, kBlock, all_lds_bytes(sc));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_all<false>, kBlock, all_lds_bytes(sc));
+      break;
     case kShade:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
       break;
@@ -2489,6 +2693,11 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
 // levels: bounces per pass the caller asks for (1 or 2); returns how many the launched kernel performs — 2 only from
 // k_bounce (the large-scene kernels trace one depth per pass) — so that the host advances its depth loop by that much.
 // cnt_mid: fill-level row of depth + 1 (two bounces per pass: receives the ray count only), cnt_out: row of depth + levels.
+void launch_bounce_all(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret) {
+  const int bytes = all_lds_bytes(sc);
+  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce_all<true>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
+  else hipLaunchKernelGGL(k_bounce_all<false>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
+}
 int launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, int levels, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
   if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL(k_bounce_big<true>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
@@ -2605,7 +2814,7 @@ const KernelApi kApi = {
     "fast",
 #endif
     launch_generate, launch_primary, launch_bounce, launch_intersect, launch_shade, launch_collect, launch_count_stats,
-    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check};
+    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check, launch_bounce_all};
 
 }  // namespace
 }  // namespace PT_NS
