@@ -594,7 +594,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   int src = d0 & 1;
   // debug_flags 4096 (experiment): all depths >= 1 in ONE launch of k_bounce_all — persistent lanes with their own depth, no
   // path state through HBM after depth 0 (small-scene kernels only)
-  const bool all_depths = (g.debug_flags & 4096) && g.fuse_primary && g.fuse_bounces && g.grid_bounce_all > 0 && !sc.big_kernel && g.depth > 1 && g.depth <= 9;  // (the kernel counts rays per depth for depths 1..8)
+  const bool all_depths = (g.debug_flags & 4096) && g.fuse_primary && g.fuse_bounces && g.grid_bounce_all > 0 && !sc.big_kernel && g.depth > 1 && g.depth <= 16;  // (the kernel's per-depth statistics cover depths 1..15)
   if (all_depths) {
     EventPair ev{};
     if (g.time_kernels) {

@@ -2101,7 +2101,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
     tbl += nb_nodes + nb_geoms;
   }
-  constexpr int kFifoBytes = 6 * 64 * 4;
+  constexpr int kFifoBytes = 6 * 64 * 4 + 64;  // + 16 counters: paths retired per depth (statistics)
   const int wave_bytes = carry_bytes<TABLES_IN_LDS>() + kFifoBytes;
   // iteration-hash rows of the depths 1 .. trace_depth - 1 behind the per-wave blocks
   const int he = iter_hash_entries(sc);
@@ -2111,10 +2111,12 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
   const int wib = threadIdx.x >> 6;
   Carry<TABLES_IN_LDS> cy = carry_init<TABLES_IN_LDS>(lds + tbl + wib * wave_bytes);
   float* fifo = reinterpret_cast<float*>(lds + tbl + wib * wave_bytes + carry_bytes<TABLES_IN_LDS>());  // [6][64]: o.xyz, d.xyz of the next 64 rays
+  int* died = reinterpret_cast<int*>(fifo + 6 * 64);  // [16]: paths of this wave retired AT depth d (d = 1 .. 15; deeper ones in [15])
   cy.debug = b.debug;
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
+  if (lane < 16) died[lane] = 0;
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
   const size_t per_depth = (size_t)qs.Q * qs.cnt_stride;
@@ -2128,6 +2130,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
   struct Group {
     f3 o, d, c;
     int slot, depth;
+    uint32_t phash;  // utilhash(global pixel index): the per-pixel half of the RNG seed, computed once per path
     bool valid, pending;
     int mark;
   };
@@ -2135,7 +2138,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     G[p].o = G[p].d = G[p].c = mk(0.f, 0.f, 0.f);
-    G[p].slot = 0, G[p].depth = 1, G[p].valid = false, G[p].pending = false, G[p].mark = 0;
+    G[p].slot = 0, G[p].depth = 1, G[p].phash = 0u, G[p].valid = false, G[p].pending = false, G[p].mark = 0;
   }
   // FIFO: rays given .. given + 63 (clamped into the slice; slots beyond `hi` are never consumed)
   auto load_od = [&](int i, f3& o, f3& d) {
@@ -2151,7 +2154,6 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
     fifo[3 * 64 + lane] = sd.x, fifo[4 * 64 + lane] = sd.y, fifo[5 * 64 + lane] = sd.z;
   }
   int streamed = min(lo + 64, hi);  // rays whose (o, d) are in the FIFO or staged: [given, streamed)
-  unsigned int traced[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // rays searched per depth (statistics), depths 1..8 -> [0..7]; deeper ones in [7]
   auto refill = [&](Group& g) {
     // 1. last refill's top-up has landed: into the FIFO
     if (staged > 0) {
@@ -2180,6 +2182,7 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
         plane2_load(in, at, cz, tg);
         g.c = mk(w1.z, w1.w, cz);
         g.slot = tg.slot;
+        g.phash = utilhash((uint32_t)global_pixel(b, tg.slot & ((1 << b.slot_shift) - 1)));
         g.depth = 1;
         g.valid = true;
       }
@@ -2200,8 +2203,6 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
     const unsigned long long v = __ballot(g.valid);
     g.pending = v != 0ull;
     if (!g.pending) return;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) traced[d] += (unsigned int)__popcll(__ballot(g.valid && (d < 7 ? g.depth == d + 1 : g.depth >= 8)));
     cy.best[par * 64 + lane] = kNoHit;
     carry_search<!TABLES_IN_LDS, 2>(cy, top, ntop, nodes, geoms, g.o, g.d, g.valid, lane, par, sc.cull_margin, sc.top_xor);
     g.mark = cy.appended;
@@ -2233,13 +2234,13 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
         hn = mk(rr[0 * 64], rr[1 * 64], rr[2 * 64]);
         hp = mk(rr[3 * 64], rr[4 * 64], rr[5 * 64]);
       }
-      const uint32_t ph = utilhash((uint32_t)global_pixel(b, pl));
       const uint32_t ih = he > 0 ? ihash[(g.depth - 1) * he + k] : iter_hash(b.iter_first + k, g.depth);
-      bo = shade_decide(mats, b.trace_depth, g.depth, ih ^ ph, ht, hmat, s);
+      bo = shade_decide(mats, b.trace_depth, g.depth, ih ^ g.phash, ht, hmat, s);
     }
     const bool alive = g.valid && s.alive, dead = g.valid && !s.alive;
     const int rpos = retire_reserve(rt, dead, k);
     retire_store(rt, dead, k, rpos, pl, s.c);
+    if (dead) atomicAdd(&died[min(g.depth, 15)], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
     if (alive) shade_bounce(bo, hn, hp, s);
     g.o = s.o, g.d = s.d, g.c = s.c;
     g.depth += 1;
@@ -2254,10 +2255,14 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
     shade(G[0], 0);
     if (!__ballot(G[0].valid || G[1].valid)) break;  // every path of the slice has retired (a refill would have revived a lane)
   }
-  // statistics: rays traced per depth >= 2 (row 1 holds the queue's input count already)
-  if (lane == 0)
-    for (int d = 2; d < b.trace_depth && d <= 8; ++d)
-      if (traced[d - 1]) atomicAdd(&cnt[per_depth * d + (size_t)q * qs.cnt_stride], (int)traced[d - 1]);
+  // statistics: rays traced at depth d >= 2 = this wave's paths retired at depth >= d (row 1 holds the queue's input count already)
+  if (lane == 0) {
+    int reached = 0;
+    for (int d = min(b.trace_depth - 1, 15); d >= 2; --d) {
+      reached += died[d];
+      if (reached) atomicAdd(&cnt[per_depth * d + (size_t)q * qs.cnt_stride], reached);
+    }
+  }
   retire_end(rt, ret, b, q, r, lane);
 }
 
@@ -2579,7 +2584,7 @@ int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool prima
 int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
 int all_lds_bytes(const SceneTables& sc) {  // one iteration-hash row is in fused_lds_bytes already
-  return fused_lds_bytes(sc, tables_in_lds(sc), (tables_in_lds(sc) ? carry_bytes<true>() : carry_bytes<false>()) + 6 * 64 * 4) +
+  return fused_lds_bytes(sc, tables_in_lds(sc), (tables_in_lds(sc) ? carry_bytes<true>() : carry_bytes<false>()) + 6 * 64 * 4 + 64) +
          iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 2);
 }
 int big_lds_bytes(const SceneTables& sc) {

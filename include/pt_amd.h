@@ -103,7 +103,9 @@ typedef struct PtOptions {
                                forbid the uniform-grid walk of the fused kernels (default: for large scenes, whichever of
                                the BVH scan and up to three grid resolutions renders a few iterations fastest at pt_init), 1024 two bounces per pass in the fused
                                bounce kernel of small scenes (the survivors of every other depth stay in registers instead of
-                               going through HBM; measured slower, kept as an experiment), 2048 keep the reference's
+                               going through HBM; measured slower, kept as an experiment), 4096 all depths >= 1 of a batch in ONE launch (k_bounce_all: persistent lanes with their own depth, a dead
+                               lane takes the next depth-1 ray of its queue, no path state through HBM after depth 0; small-scene
+                               kernels, trace depth <= 16; an experiment: same image and statistics, same speed), 2048 keep the reference's
                                leaf boxes for spheres (default for large scenes: tightened to the ellipsoid's box, PtStats.tight_leaves;
                                pt_stage_intersect on such a scene then expects ray origins inside the scene bounds or at the camera).  Bits 0-3 are profiling ablations with WRONG results
                                (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
