@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
                                  C.POINTER(C.c_long)]
         L.orc_math_eval_f.argtypes = [C.c_int, C.c_int, fp, fp]
         L.orc_math_eval_d.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_aabb_all_nodes.argtypes = [C.c_int, fp, fp, C.POINTER(C.c_uint32)]
+        L.orc_helpers.argtypes = [C.c_int, C.c_int, fp, fp]
         L.orc_build_xform.argtypes = [fp, fp, fp, fp]
         L.orc_vecops.argtypes = [fp, fp, fp, fp]
         _lib = L
@@ -225,4 +227,22 @@ def vecops(a, b, m16):
     out = np.zeros(14, np.float32)
     lib().orc_vecops(_fp(np.ascontiguousarray(a, np.float32)), _fp(np.ascontiguousarray(b, np.float32)),
                      _fp(np.ascontiguousarray(m16, np.float32)), _fp(out))
+    return out
+
+
+def aabb_all_nodes(o: np.ndarray, d: np.ndarray) -> np.ndarray:
+    """intersectAABB of rays o, d [n, 3] against every node box of the loaded scene: uint32 [n, ceil(nodes / 32)] bit rows."""
+    o = np.ascontiguousarray(o, np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    words = (lib().orc_num_bvh_nodes() + 31) // 32
+    out = np.zeros((len(o), words), np.uint32)
+    lib().orc_aabb_all_nodes(len(o), _fp(o), _fp(d), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def helpers(kind: int, inputs: np.ndarray) -> np.ndarray:
+    """The sampling helpers of pathtrace.cu:216-242 in the current math mode (0 frame, 1 cosine-weighted sample, 2 reflect)."""
+    x = np.ascontiguousarray(inputs, np.float32)
+    out = np.zeros((len(x), 6 if kind == 0 else 3), np.float32)
+    lib().orc_helpers(kind, len(x), _fp(x), _fp(out))
     return out

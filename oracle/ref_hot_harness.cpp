@@ -13,11 +13,12 @@
 // the include.  `new Scene(path)` is used exactly as main.cpp:45 does, so the undefined Scene::~Scene (scene.h:21) is
 // never needed.
 //
-// What can NOT be compiled here, and therefore stays pinned by restatement + SURVEY §4 KATs: src/pathtrace.cu itself
-// (kernel launch syntax, <cuda.h>, CUDA Thrust): the BVH builder, the traversal order, intersectAABB, the shading
-// kernel, main.cpp's camera fix-up.  The one formula of pathtrace.cu this harness restates is the seed expression of
-// makeSeededRandomEngine (pathtrace.cu:205) — around the reference's own utilhash — to produce the seed list that
-// ref_rng_harness.cpp feeds to rocThrust's minstd_rand.
+// What of src/pathtrace.cu is pinned where: its plain-C++ functions (buildBVH / computeBounds, intersectAABB, the sampling
+// helpers) are compiled from the file's own text by ref_pt_harness.cpp; its __global__ bodies (computeIntersections' stack
+// walk, shadeAndExtendRays, finalGather) and main.cpp's camera fix-up compile with neither g++ nor clang's CUDA mode without
+// stand-ins for the CUDA toolchain and stay pinned by restatement + SURVEY §4 KATs.  The one formula of pathtrace.cu this
+// harness restates is the seed expression of makeSeededRandomEngine (pathtrace.cu:205) — around the reference's own
+// utilhash — to produce the seed list that ref_rng_harness.cpp feeds to rocThrust's minstd_rand.
 //
 // Modes:
 //   ref_hot scene OUT.json SCENE.txt...        dump geoms / materials / camera / render state as the reference's loader
