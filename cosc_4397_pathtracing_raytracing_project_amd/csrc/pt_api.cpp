@@ -120,7 +120,7 @@ struct PtContext {
   bool fuse_primary = true, fuse_bounces = true;
   bool aa_jitter = false;
   bool has_triangles = false;  // SceneTables::has_triangles
-  int grid_primary = 0, grid_bounce = 0, grid_bounce_all = 0;
+  int grid_primary = 0, grid_bounce = 0, grid_paths = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
   ptd::RetireBuf ret{};  // retirement records + fill levels (pt_device.h)
@@ -592,16 +592,16 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   // slower than one per pass, DESIGN.md section 5, so not the default): the input alternates between the two path buffers
   // per LAUNCH, not per depth
   int src = d0 & 1;
-  // debug_flags 4096 (experiment): all depths >= 1 in ONE launch of k_bounce_all — persistent lanes with their own depth, no
-  // path state through HBM after depth 0 (small-scene kernels only)
-  const bool all_depths = (g.debug_flags & 4096) && g.fuse_primary && g.fuse_bounces && g.grid_bounce_all > 0 && !sc.big_kernel && g.depth > 1 && g.depth <= 16;  // (the kernel's per-depth statistics cover depths 1..15)
+  // Depths >= 1 of the LDS-table scenes: ONE launch of k_paths — persistent lanes with their own depth, no path state through
+  // HBM after depth 0 (plan_launch decides: grid_paths > 0; debug_flags 4096 keeps the per-depth k_bounce launches, same image)
+  const bool all_depths = g.grid_paths > 0;
   if (all_depths) {
     EventPair ev{};
     if (g.time_kernels) {
       if (get_events(g, &ev)) return -1;
       HIP_OK(hipEventRecord(ev.a, g.stream));
     }
-    k.bounce_all(g.stream, g.grid_bounce_all, sc, b, queues_for(g, g.grid_bounce_all), g.d_cnt, g.buf[1], g.ret);
+    k.paths(g.stream, g.grid_paths, sc, b, queues_for(g, g.grid_paths), g.d_cnt, g.buf[1], g.ret);
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
       g.pending_isect.push_back(ev);
@@ -666,7 +666,9 @@ void plan_launch(Ctx& g) {
   g.grid_shade = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kShade, t));
   g.grid_primary = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
   g.grid_bounce = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounce, t));
-  g.grid_bounce_all = (g.debug_flags & 4096) ? g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounceAll, t)) : 0;
+  // (k_paths' per-depth statistics cover depths 1..15)
+  const bool paths = g.fuse_primary && g.fuse_bounces && !(g.debug_flags & 4096) && t.lds_table_bytes >= 0 && !t.big_kernel && g.depth > 1 && g.depth <= 16;
+  g.grid_paths = paths ? g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPaths, t)) : 0;
 }
 
 // Make candidate i the grid the kernels walk.
@@ -1249,7 +1251,7 @@ int pt_ctx_get_stats(PtContext* c, PtStats* out) {
   out->intersect_ms = g.isect_ms;
   out->render_ms = g.render_ms;
   out->num_cus = g.num_cus;
-  out->grid_blocks = g.fuse_bounces ? g.grid_bounce : g.grid_isect;
+  out->grid_blocks = g.grid_paths > 0 ? g.grid_paths : (g.fuse_bounces ? g.grid_bounce : g.grid_isect);
   out->num_queues = g.qs.Q;
   out->iters_per_batch = g.K;
   out->device_bytes = g.device_bytes;

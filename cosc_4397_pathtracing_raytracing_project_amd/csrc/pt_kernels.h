@@ -53,7 +53,7 @@ struct SceneTables {
   float grid_min[3], grid_cs[3], grid_inv_cs[3];
   float grid_pad;
   int32_t use_grid;
-  int32_t trace_depth;    // of the context (k_bounce_all sizes its iteration-hash rows with it)
+  int32_t trace_depth;    // of the context (k_paths sizes its iteration-hash rows with it)
   int32_t has_triangles;  // mesh extension: some geoms are PT_GEOM_TRIANGLE (the sphere-only chunk specialisation is off)
 };
 
@@ -76,7 +76,7 @@ struct BatchInfo {
 // Resident workgroups per CU for each persistent kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor),
 // so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
 // a workgroup that has to wait for a free slot would run its whole share after everybody else.
-enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kBounce = 5, kBounceAll = 6 };
+enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kBounce = 5, kPaths = 6 };
 
 // pt_kernels.hip is compiled once per arithmetic mode (PtOptions.arith, include/pt_amd.h):
 //   0 exact  -ffp-contract=off, every operation in the reference's order: bit-identical to oracle/pt_oracle.cpp
@@ -133,10 +133,10 @@ struct KernelApi {
   // Self-check of the guarded IEEE square root / reciprocal / quotient sequences (pt_kernels.hip namespace ieee) against the
   // compiler's expansions on `count` operands starting at `first`; adds the number of mismatching results to *bad.
   void (*ieee_check)(hipStream_t s, int kind, unsigned long long first, unsigned long long count, uint32_t seed, unsigned long long* bad);
-  // Experiment (PtOptions.debug_flags 4096): ALL depths >= 1 of a batch in one launch — persistent lanes with their own depth,
-  // a dead lane takes the next depth-1 ray of its queue, survivors never leave their registers (pt_kernels.hip k_bounce_all).
-  // cnt = the counter rows [depth][Q]: row 1 is read (the queues' depth-1 rays), rows >= 2 receive the rays traced per depth.
-  void (*bounce_all)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret);
+  // ALL depths >= 1 of a batch in ONE launch — persistent lanes with their own depth, a dead lane takes the next depth-1 ray of its
+  // queue, survivors never leave their registers (pt_kernels.hip k_paths; LDS-table scenes).  cnt = the counter rows [depth][Q]:
+  // row 1 is read (the queues' depth-1 rays), rows >= 2 receive the rays traced per depth.
+  void (*paths)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret);
 };
 const KernelApi* api_exact();
 const KernelApi* api_fma();

@@ -275,7 +275,7 @@ struct RayInv {
 #pragma clang fp contract(off)
 namespace ex {
 namespace {
-constexpr bool kFastDiv = false, kFastSqrt = false, kFastMV = false, kFastRenorm = false, kFastSlab = false, kFastQO = true, kFastPoint = false;
+constexpr bool kFastDiv = false, kFastSqrt = false, kFastMV = false, kFastRenorm = false, kFastSlab = false, kFastQO = true, kFastPoint = false, kFusedRef = false;
 #include "pt_arith.inc"
 }  // namespace
 }  // namespace ex
@@ -285,7 +285,7 @@ constexpr bool kFastDiv = false, kFastSqrt = false, kFastMV = false, kFastRenorm
 namespace md {
 namespace {
 constexpr bool kFastDiv = PT_NS::kFastDiv, kFastSqrt = PT_NS::kFastSqrt, kFastMV = PT_NS::kFastMV, kFastRenorm = PT_NS::kFastRenorm,
-               kFastSlab = PT_NS::kFastSlab, kFastQO = PT_NS::kFastQO, kFastPoint = PT_NS::kFastPoint;
+               kFastSlab = PT_NS::kFastSlab, kFastQO = PT_NS::kFastQO, kFastPoint = PT_NS::kFastPoint, kFusedRef = PT_ARITH == 1;
 #include "pt_arith.inc"
 }  // namespace
 }  // namespace md
@@ -2065,22 +2065,163 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
   retire_end(rt, ret, b, q, r, lane);
 }
 
-// ── ALL depths >= 1 in one launch (experiment, debug_flags 4096; LDS-table scenes) ────────────────────────────────────────
-// k_bounce runs at 83 % of the speed of a kernel that only moves its bytes, so the way up is fewer
-// bytes: here a path never goes back to HBM.  A wave keeps two persistent groups of 64 lanes; a lane carries its ray, its
-// throughput, its sample id and ITS OWN depth.  When a path dies the lane writes the 16-byte retirement record and takes the
-// next depth-1 ray of the wave's slice of its queue (k_primary's output); survivors stay where they are, at depth + 1.  The
-// search, the candidate ring and the primitive-test chunks are per ray already (candidates carry their owner lane and group),
-// the RNG is keyed per lane by (iteration, pixel, depth), the retirement records by iteration: nothing else changes, and
-// neither can the results.  Traffic per bounce ray: the 40-byte read and the 16-byte record of its PATH, once.
-//   * refill without a stall: the next 64 rays' (o, d) wait in an LDS ring (1.5 KB per wave); a dead lane of rank r takes
-//     slot head + r, its colour / sample id come straight from memory (first needed two searches later), and the ring is
-//     topped up with loads issued now and written to LDS at the NEXT refill, one search later.
-//   * the group searched in an iteration is shaded in the next one, after the other group's search has pushed its last
-//     candidates through the ring (as in k_bounce), then refilled.
+// ── ALL depths >= 1 in one launch: persistent lanes (k_paths) ─────────────────────────────────────────────────────────────────
+// After depth 0 a path never goes back to HBM.  A wave has ONE set of 64 lanes; a lane carries its ray, its throughput, its
+// sample id and ITS OWN depth.  When a path dies the lane writes the 16-byte retirement record and takes the next depth-1 ray
+// of the wave's slice of its queue (k_primary's output); survivors stay where they are, at depth + 1.  The search, the
+// candidate ring and the primitive-test chunks are per ray (candidates carry their owner lane), the RNG is keyed per lane by
+// (iteration, pixel, depth), the retirement records by iteration: the results cannot differ from the per-depth kernels'.
+// Traffic per PATH: its 40-byte depth-1 record read once, its 16-byte retirement record written once.
+//   * per-LANE resolution: primitive tests only ever run as full 64-entry chunks, so a search leaves < 64 candidates in the
+//     ring.  A lane is shaded as soon as the ring has processed the last candidate it filed (`mark`); the few lanes whose last
+//     candidate is still pending sit out this round (~3 of 64 on cornell.txt) and are shaded in the next one, after the new
+//     rays' candidates have pushed theirs through a full chunk.  (Rounds 1-3 kept two groups per wave for this and shaded a
+//     group one iteration after its search: twice the lane state and LDS, four resident workgroups per CU instead of six.)
+//   * refill: every lane owns a 40-byte LDS slot holding the NEXT path record it will take; the slot is filled by the
+//     gfx950 LDS-direct loads (global_load_lds_dwordx4 / _dword: memory -> LDS without passing through VGPRs, LDS address =
+//     M0 + lane * size), issued when the lane takes the previous one, i.e. at least a whole iteration before it is read.
+//     The loads are inline assembly: the compiler's handling of the builtin either waits for the transfer at the very next
+//     LDS access (it cannot tell the slot from the rest of the dynamic LDS) or does not compile under a divergent branch,
+//     so the transfer, its s_waitcnt and the slot reads are all spelled out here.
+//   * every vector-memory operation outstanding at the refill's s_waitcnt vmcnt(0) is a whole iteration old: the retirement
+//     store of a lane that died is issued AFTER the slot reads of the next refill (the dead lane's colour and sample id
+//     stay in its registers until then).
+#ifndef PT_PATHS_WAVES
+#define PT_PATHS_WAVES 6
+#endif
+#ifndef PT_PATHS_MIN_READY
+#define PT_PATHS_MIN_READY 32  // fewer resolved lanes than this and candidates pending: run the partial chunk instead of shading a thin group
+#endif
+constexpr int kPathsWaves = PT_PATHS_WAVES, kPathsMinReady = PT_PATHS_MIN_READY;
+constexpr int kSlotBytes = 64 * 16 + 64 * 16 + 64 * 4 + 64 * 4;  // planes 0, 1 (16 B per lane), colour.z, sample id
+constexpr int kPathsExtra = kSlotBytes + 64;                      // + 16 counters: paths retired per depth (statistics)
+typedef float v4f __attribute__((ext_vector_type(4)));
+PT_DEV uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+// memory -> LDS without passing through VGPRs: path record i of a queue (b0 / b1 / b2 = the queue's first record in planes 0,
+// 1, 2; wave-uniform, so they are scalar bases and a lane supplies 32-bit byte offsets only) of every active lane to lds_base
+// (wave-uniform) + {0, 1024} + lane * 16 (planes 0 and 1) and + {2048, 2304} + lane * 4 (colour.z, sample id).  The
+// instruction's immediate offset moves BOTH addresses, hence M0 + 0xfc for the last transfer.  M0 (the transfers' LDS base)
+// belongs to the compiler: saved and restored.
+template <typename T>
+PT_DEV const T* uniform_ptr(const T* p) {  // a pointer the compiler cannot prove wave-uniform (derived from threadIdx.x >> 6), into scalar registers
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return reinterpret_cast<const T*>((uintptr_t)(((uint64_t)hi << 32) | lo));
+}
+PT_DEV void fetch_record_to_lds(const void* b0, const void* b1, const void* b2, int i, uint32_t lds_base) {
+  uint32_t keep;
+  const uint32_t off16 = (uint32_t)i << 4, off8 = (uint32_t)i << 3;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[base]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o16], %[b0]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o16], %[b1]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %[o8], %[b2]\n\t"
+      "s_add_u32 m0, m0, 0xfc\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %[o8], %[b2] offset:4\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [base] "s"(lds_base), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [o16] "v"(off16), [o8] "v"(off8)
+      : "memory", "scc");
+}
+// __ballot() of the HIP headers goes through an integer compare (v_cndmask 0 / 1 + v_cmp per call when the predicate already
+// sits in a scalar register pair); the builtin takes the predicate as it is.
+PT_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// mask * 2 + bit in ONE instruction: v_addc_co_u32 takes the predicate as its carry-in (instead of v_mov + v_cndmask + v_or
+// per box test).  The bits end up in reverse order of the pushes.
+PT_DEV uint32_t push_bit(uint32_t m, bool bit) {
+  uint32_t r;
+  unsigned long long carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(ballot(bit)));
+  return r;
+}
+// Per-wave LDS of k_paths: closest-hit keys, winner records, the candidate ring (32-bit entries: leaf | geom << 8 | owner lane
+// << 16 — the geom index rides along, so a chunk does not go through nodes[leaf]) and the running totals.  The rays are NOT
+// kept in LDS: the lanes are persistent, a chunk fetches a candidate's ray from its owner's registers (ds_bpermute).
+struct Lanes {
+  unsigned long long* best;  // [64]
+  float* rec;                // [6][64]  normal xyz, point xyz
+  uint32_t* ent;             // [kRing]
+  int head, count;           // wave-uniform
+  int appended, processed;   // running totals (wave-uniform)
+};
+constexpr int kLanesBytes = 64 * 8 + 6 * 64 * 4 + kRing * 4;
+// Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all 64 lanes active.
+PT_DEV void paths_chunk(Lanes& c, int n, int lane, f3 o, f3 d, const ptd::Geom* __restrict__ geoms) {
+  const bool valid = lane < n;
+  const uint32_t entry = c.ent[(c.head + lane) & (kRing - 1)];
+  const int src = (int)(entry >> 16) & 63;
+  const uint32_t leaf = entry & 255u;
+  const f3 ro = mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
+  const f3 rd = mk(bperm(src, d.x), bperm(src, d.y), bperm(src, d.z));
+  const ptd::Geom* G = geoms + (valid ? (int)((entry >> 8) & 255u) : 0);
+  f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
+  const float t = geom_test<-1, false>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f));
+  const uint32_t tb = __float_as_uint(t);
+  if (valid && t > 0.f && tb < 0x7f7fffffu) {
+    const unsigned long long key = ((unsigned long long)tb << 32) | leaf;
+    unsigned long long* slot = &c.best[src];
+    atomicMin(slot, key);
+    if (*slot == key) {  // this candidate is the ray's best so far: publish its record
+      float* r = c.rec + src;
+      r[0 * 64] = nrm.x, r[1 * 64] = nrm.y, r[2 * 64] = nrm.z;
+      r[3 * 64] = pt.x, r[4 * 64] = pt.y, r[5 * 64] = pt.z;
+    }
+  }
+  c.head = (c.head + n) & (kRing - 1);
+  c.count -= n;
+  c.processed += n;
+}
+// Candidate search of the fresh lanes of a persistent group (LDS-table scenes: every top entry is a leaf) — carry_search's
+// two-phase form with the per-lane resolution mark: `mark` = ring entries appended up to and including the lane's last one.
+// tword[e] = leaf | geom << 8 of top entry e.
+PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int ntop, const ptd::Geom* __restrict__ geoms, f3 o, f3 d,
+                         bool fresh, int lane, int& mark) {
+  const RayInv ri = ray_inv(d, o);
+  if (fresh) {
+    c.best[lane] = kNoHit;
+    mark = c.processed;  // no candidate: resolved at once
+  }
+  // box tests, eight at a time fully unrolled (no loop-carried box registers to rotate); bit (ntop - 1 - e) of the mask = entry e
+  uint32_t mask = 0;
+  for (int e0 = 0; e0 < ntop; e0 += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u;
+      if (e < ntop) {
+        const float4 A = top[2 * e], B = top[2 * e + 1];
+        mask = push_bit(mask, slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y));
+      }
+    }
+  }
+  mask = fresh ? mask : 0u;
+  const uint32_t tag = (uint32_t)lane << 16;
+  while (true) {
+    const unsigned long long m = ballot(mask != 0u);
+    if (!m) break;
+    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    if (mask != 0u) {
+      const int te = ntop - 1 - __builtin_ctz(mask);
+      mask &= mask - 1u;
+      c.ent[(c.head + c.count + rank) & (kRing - 1)] = tword[te] | tag;
+      if (mask == 0u) mark = c.appended + rank + 1;
+    }
+    const int cnt = __popcll(m);
+    c.count += cnt;
+    c.appended += cnt;
+    if (c.count >= 64) paths_chunk(c, 64, lane, o, d, geoms);
+  }
+}
 template <bool TABLES_IN_LDS>
-__global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
-                                                                     ptd::PathBuf in, ptd::RetireBuf ret) {
+__global__ __launch_bounds__(kBlock, kPathsWaves) void k_paths(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
+                                                               ptd::PathBuf in, ptd::RetireBuf ret) {
+  static_assert(TABLES_IN_LDS, "k_paths: LDS-table scenes (every leaf a top entry)");
   extern __shared__ float4 lds_raw[];
   char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);
   const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
@@ -2089,30 +2230,37 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
   stage16(lds + nb_top, sc.mats, nb_mats);
   const float4* top = reinterpret_cast<const float4*>(lds);
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
-  const ptd::Node* nodes = sc.nodes;
-  const ptd::Geom* geoms = sc.geoms;
   int tbl = nb_top + nb_mats;
-  if (TABLES_IN_LDS) {
-    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
-    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
-    stage16(lds + tbl, sc.nodes, nb_nodes);
-    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
-    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
-    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
-    tbl += nb_nodes + nb_geoms;
-  }
-  constexpr int kFifoBytes = 6 * 64 * 4 + 64;  // + 16 counters: paths retired per depth (statistics)
-  const int wave_bytes = carry_bytes<TABLES_IN_LDS>() + kFifoBytes;
-  // iteration-hash rows of the depths 1 .. trace_depth - 1 behind the per-wave blocks
+  const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+  const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
+  stage16(lds + tbl, sc.nodes, nb_nodes);
+  stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
+  const ptd::Node* nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
+  const ptd::Geom* geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
+  tbl += nb_nodes + nb_geoms;
+  constexpr int wave_bytes = kLanesBytes + kPathsExtra;
   const int he = iter_hash_entries(sc);
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * wave_bytes);
+  uint32_t* tword = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * wave_bytes);  // [kMaxTop]: leaf | geom << 8 per top entry
+  int* lmat = reinterpret_cast<int*>(tword + kMaxTop);                                      // [64]: material of the leaf at threaded node index i
+  uint32_t* ihash = tword + kMaxTop + 64;                                                   // rows of the depths 1 .. trace_depth - 1
   for (int d = 1; d < b.trace_depth; ++d) iter_hash_fill(ihash + (d - 1) * he, sc, b, d);
+  for (int e = threadIdx.x; e < sc.num_top; e += blockDim.x) {
+    const int leaf = sc.top[e].idx, gi = sc.nodes[leaf].geom;
+    tword[e] = (uint32_t)leaf | ((uint32_t)gi << 8);
+    lmat[leaf & 63] = sc.geoms[gi].material;
+  }
   __syncthreads();
   const int wib = threadIdx.x >> 6;
-  Carry<TABLES_IN_LDS> cy = carry_init<TABLES_IN_LDS>(lds + tbl + wib * wave_bytes);
-  float* fifo = reinterpret_cast<float*>(lds + tbl + wib * wave_bytes + carry_bytes<TABLES_IN_LDS>());  // [6][64]: o.xyz, d.xyz of the next 64 rays
-  int* died = reinterpret_cast<int*>(fifo + 6 * 64);  // [16]: paths of this wave retired AT depth d (d = 1 .. 15; deeper ones in [15])
-  cy.debug = b.debug;
+  Lanes cy;
+  {
+    char* base = lds + tbl + wib * wave_bytes;
+    cy.best = reinterpret_cast<unsigned long long*>(base);
+    cy.rec = reinterpret_cast<float*>(base + 64 * 8);
+    cy.ent = reinterpret_cast<uint32_t*>(base + 64 * 8 + 6 * 64 * 4);
+    cy.head = cy.count = cy.appended = cy.processed = 0;
+  }
+  char* slots = lds + tbl + wib * wave_bytes + kLanesBytes;  // [64] x 16 B, [64] x 16 B, [64] x 4 B, [64] x 4 B
+  int* died = reinterpret_cast<int*>(slots + kSlotBytes);    // [16]: paths of this wave retired AT depth d (deeper than 15: in [15])
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
@@ -2125,142 +2273,109 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce_all(SceneTables
   // the wave's slice of the queue's input
   const int per = (n_q + wq - 1) / wq;
   const int lo = min(r * per, n_q), hi = min(lo + per, n_q);
-  int given = lo;   // rays handed to lanes so far: [lo, given)
-  int head = 0;     // FIFO slot of ray `given`
-  struct Group {
-    f3 o, d, c;
-    int slot, depth;
-    uint32_t phash;  // utilhash(global pixel index): the per-pixel half of the RNG seed, computed once per path
-    bool valid, pending;
-    int mark;
-  };
-  Group G[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    G[p].o = G[p].d = G[p].c = mk(0.f, 0.f, 0.f);
-    G[p].slot = 0, G[p].depth = 1, G[p].phash = 0u, G[p].valid = false, G[p].pending = false, G[p].mark = 0;
-  }
-  // FIFO: rays given .. given + 63 (clamped into the slice; slots beyond `hi` are never consumed)
-  auto load_od = [&](int i, f3& o, f3& d) {
-    const int64_t at = qbase + min(max(i, lo), max(hi - 1, lo));
-    const ptd::Word4 w0 = in.r[at], w1 = in.r[in.stride + at];
-    o = mk(w0.x, w0.y, w0.z), d = mk(w0.w, w1.x, w1.y);
-  };
-  f3 so, sd;  // top-up staging (registers): the rays that replace the slots consumed by the previous refill
-  int staged = 0, staged_at = 0;  // their count and first FIFO slot
-  if (hi > lo) {
-    load_od(lo + lane, so, sd);
-    fifo[0 * 64 + lane] = so.x, fifo[1 * 64 + lane] = so.y, fifo[2 * 64 + lane] = so.z;
-    fifo[3 * 64 + lane] = sd.x, fifo[4 * 64 + lane] = sd.y, fifo[5 * 64 + lane] = sd.z;
-  }
-  int streamed = min(lo + 64, hi);  // rays whose (o, d) are in the FIFO or staged: [given, streamed)
-  auto refill = [&](Group& g) {
-    // 1. last refill's top-up has landed: into the FIFO
-    if (staged > 0) {
-      if (lane < staged) {
-        const int sl = (staged_at + lane) & 63;
-        fifo[0 * 64 + sl] = so.x, fifo[1 * 64 + sl] = so.y, fifo[2 * 64 + sl] = so.z;
-        fifo[3 * 64 + sl] = sd.x, fifo[4 * 64 + sl] = sd.y, fifo[5 * 64 + sl] = sd.z;
-      }
-      staged = 0;
-    }
-    // 2. dead lanes take the next rays
-    const unsigned long long dead = __ballot(!g.valid);
-    const int want = __popcll(dead);
-    const int n = min(want, streamed - given);  // only rays whose (o, d) are already in the FIFO
-    if (n > 0) {
-      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(dead >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dead, 0));
-      const bool take = !g.valid && rank < n;
-      if (take) {
-        const int sl = (head + rank) & 63;
-        g.o = mk(fifo[0 * 64 + sl], fifo[1 * 64 + sl], fifo[2 * 64 + sl]);
-        g.d = mk(fifo[3 * 64 + sl], fifo[4 * 64 + sl], fifo[5 * 64 + sl]);
-        const int64_t at = qbase + given + rank;
-        const ptd::Word4 w1 = in.r[in.stride + at];
-        PathTag tg;
-        float cz;
-        plane2_load(in, at, cz, tg);
-        g.c = mk(w1.z, w1.w, cz);
-        g.slot = tg.slot;
-        g.phash = utilhash((uint32_t)global_pixel(b, tg.slot & ((1 << b.slot_shift) - 1)));
-        g.depth = 1;
-        g.valid = true;
-      }
-      // 3. top up the consumed slots: loads now, LDS write at the next refill
-      if (streamed < hi) {
-        staged = min(n, hi - streamed);
-        staged_at = head;
-        if (lane < staged) load_od(streamed + lane, so, sd);
-        streamed += staged;
-      }
-      given += n;
-      head = (head + n) & 63;
-    }
-  };
-  refill(G[0]);
-  refill(G[1]);
-  auto search = [&](Group& g, int par) {
-    const unsigned long long v = __ballot(g.valid);
-    g.pending = v != 0ull;
-    if (!g.pending) return;
-    cy.best[par * 64 + lane] = kNoHit;
-    carry_search<!TABLES_IN_LDS, 2>(cy, top, ntop, nodes, geoms, g.o, g.d, g.valid, lane, par, sc.cull_margin, sc.top_xor);
-    g.mark = cy.appended;
-  };
-  auto shade = [&](Group& g, int par) {
-    if (!g.pending) return;
-    carry_drain_to(cy, g.mark, lane, nodes, geoms);
-    const unsigned long long best = cy.best[par * 64 + lane];
-    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
-    ShadeIO s;
-    s.o = mk(0.f, 0.f, 0.f);
-    s.d = g.d;
-    s.c = g.c;
-    s.alive = false;
-    Bounce bo;
-    bo.kind = 0;
-    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
-    PathTag tag;
-    tag.slot = g.slot, tag.phash = 0u, tag.k = 0;
-    int k, pl;
-    sample_of(tag, b, k, pl);
-    if (g.valid) {
-      float ht = -1.0f;
-      int hmat = 0;
-      if (hit) {
-        ht = __uint_as_float((uint32_t)(best >> 32));
-        hmat = geoms[nodes[(uint32_t)best].geom].material;
-        const float* rr = cy.rec + par * 6 * 64 + lane;
-        hn = mk(rr[0 * 64], rr[1 * 64], rr[2 * 64]);
-        hp = mk(rr[3 * 64], rr[4 * 64], rr[5 * 64]);
-      }
-      const uint32_t ih = he > 0 ? ihash[(g.depth - 1) * he + k] : iter_hash(b.iter_first + k, g.depth);
-      bo = shade_decide(mats, b.trace_depth, g.depth, ih ^ g.phash, ht, hmat, s);
-    }
-    const bool alive = g.valid && s.alive, dead = g.valid && !s.alive;
-    const int rpos = retire_reserve(rt, dead, k);
-    retire_store(rt, dead, k, rpos, pl, s.c);
-    if (dead) atomicAdd(&died[min(g.depth, 15)], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
-    if (alive) shade_bounce(bo, hn, hp, s);
-    g.o = s.o, g.d = s.d, g.c = s.c;
-    g.depth += 1;
-    g.valid = alive;
-    g.pending = false;
-    refill(g);
-  };
+  const uint32_t s_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(slots));
+  const uint32_t s16 = s_base + (uint32_t)lane * 16u, s4 = s_base + 2048u + (uint32_t)lane * 4u;
+  // issue the transfer of path record `i` of the queue into this lane's slot
+  const ptd::Word4 *in0 = uniform_ptr(in.r + qbase), *in1 = uniform_ptr(in.r + in.stride + qbase);
+  const float* in2 = uniform_ptr(reinterpret_cast<const float*>(in.r + 2 * in.stride) + 2 * qbase);
+  auto fetch = [&](int i) { fetch_record_to_lds(in0, in1, in2, i, s_base); };
+  // lane state
+  f3 o = mk(0.f, 0.f, 0.f), d = o, c = o;
+  int slot = 0, depth = 1, mark = 0, rpos = 0;
+  uint32_t phash = 0u;
+  bool valid = false, fresh = false, owes = false;  // owes: the lane's path died and its retirement record is not stored yet
+  bool has_next = lo + lane < hi;
+  if (has_next) fetch(lo + lane);
+  int streamed = min(lo + 64, hi);  // records handed to slots so far: [lo, streamed)
   while (true) {
-    search(G[0], 0);
-    shade(G[1], 1);
-    search(G[1], 1);
-    shade(G[0], 0);
-    if (!__ballot(G[0].valid || G[1].valid)) break;  // every path of the slice has retired (a refill would have revived a lane)
+    // ── refill: dead lanes take the record waiting in their slot; the slot gets the next record of the slice ──
+    const bool take = !valid && has_next;
+    const unsigned long long tm = ballot(take);
+    if (tm | ballot(owes)) {
+      v4f w0, w1;
+      float cz;
+      int nslot;
+      // everything outstanding here (last refill's transfers, last refill's retirement stores) is a whole iteration old
+      asm volatile(
+          "s_waitcnt vmcnt(0)\n\t"
+          "ds_read_b128 %0, %4\n\t"
+          "ds_read_b128 %1, %4 offset:1024\n\t"
+          "ds_read_b32 %2, %5\n\t"
+          "ds_read_b32 %3, %5 offset:256\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(w0), "=&v"(w1), "=&v"(cz), "=&v"(nslot)
+          : "v"(s16), "v"(s4)
+          : "memory");
+      if (owes) {  // the record of the path that died in this lane (its colour and sample id are still here)
+        const int k = (int)((uint32_t)slot >> b.slot_shift), pl = slot & ((1 << b.slot_shift) - 1);
+        retire_store(rt, true, k, rpos, pl, c);
+        owes = false;
+      }
+      if (take) {
+        o = mk(w0.x, w0.y, w0.z), d = mk(w0.w, w1.x, w1.y), c = mk(w1.z, w1.w, cz);
+        slot = nslot;
+        phash = utilhash((uint32_t)global_pixel(b, nslot & ((1 << b.slot_shift) - 1)));
+        depth = 1;
+        valid = fresh = true;
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0));
+        has_next = streamed + rank < hi;
+        if (has_next) fetch(streamed + rank);
+      }
+      streamed = min(streamed + (int)__popcll(tm), hi);
+    }
+    if (!ballot(valid)) break;  // every path of the slice has retired
+    // ── search: box tests + appends for the lanes with a new ray; full chunks as the ring fills ──
+    if (ballot(fresh)) paths_search(cy, top, tword, ntop, geoms, o, d, fresh, lane, mark);
+    fresh = false;
+    // ── which lanes are resolved?  Too few, with candidates pending: run them as a partial chunk ──
+    bool ready = valid && (cy.processed - mark) >= 0;
+    if (cy.count > 0 && __popcll(ballot(ready)) < kPathsMinReady) {
+      paths_chunk(cy, cy.count, lane, o, d, geoms);  // count < 64 here
+      ready = valid;
+    }
+    // ── shade the resolved lanes ──
+    {
+      const unsigned long long best = cy.best[lane];
+      const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+      ShadeIO s;
+      s.o = mk(0.f, 0.f, 0.f);
+      s.d = d;
+      s.c = c;
+      s.alive = false;
+      Bounce bo;
+      bo.kind = 0;
+      f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+      const int k = (int)((uint32_t)slot >> b.slot_shift);
+      if (ready) {
+        float ht = -1.0f;
+        int hmat = 0;
+        if (hit) {
+          ht = __uint_as_float((uint32_t)(best >> 32));
+          hmat = lmat[(uint32_t)best & 63u];
+          const float* rr = cy.rec + lane;
+          hn = mk(rr[0 * 64], rr[1 * 64], rr[2 * 64]);
+          hp = mk(rr[3 * 64], rr[4 * 64], rr[5 * 64]);
+        }
+        const uint32_t ih = he > 0 ? ihash[(depth - 1) * he + k] : iter_hash(b.iter_first + k, depth);
+        bo = shade_decide(mats, b.trace_depth, depth, ih ^ phash, ht, hmat, s);
+      }
+      const bool alive = ready && s.alive, dead = ready && !s.alive;
+      const int rp = retire_reserve(rt, dead, k);
+      if (dead) atomicAdd(&died[min(depth, 15)], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
+      if (alive) shade_bounce(bo, hn, hp, s);
+      if (ready) {
+        c = s.c;
+        if (alive) o = s.o, d = s.d, depth += 1, fresh = true;
+        else valid = false, owes = true, rpos = rp;
+      }
+    }
   }
   // statistics: rays traced at depth d >= 2 = this wave's paths retired at depth >= d (row 1 holds the queue's input count already)
   if (lane == 0) {
     int reached = 0;
-    for (int d = min(b.trace_depth - 1, 15); d >= 2; --d) {
-      reached += died[d];
-      if (reached) atomicAdd(&cnt[per_depth * d + (size_t)q * qs.cnt_stride], reached);
+    for (int dd = min(b.trace_depth - 1, 15); dd >= 2; --dd) {
+      reached += died[dd];
+      if (reached) atomicAdd(&cnt[per_depth * dd + (size_t)q * qs.cnt_stride], reached);
     }
   }
   retire_end(rt, ret, b, q, r, lane);
@@ -2583,9 +2698,8 @@ int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool prima
 }
 int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
-int all_lds_bytes(const SceneTables& sc) {  // one iteration-hash row is in fused_lds_bytes already
-  return fused_lds_bytes(sc, tables_in_lds(sc), (tables_in_lds(sc) ? carry_bytes<true>() : carry_bytes<false>()) + 6 * 64 * 4 + 64) +
-         iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 2);
+int paths_lds_bytes(const SceneTables& sc) {  // one iteration-hash row is in fused_lds_bytes already
+  return fused_lds_bytes(sc, true, kLanesBytes + kPathsExtra) + kMaxTop * 4 + 64 * 4 + iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 2);
 }
 int big_lds_bytes(const SceneTables& sc) {
   if (sc.use_grid)
@@ -2652,9 +2766,9 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true, false>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
       break;
-    case kBounceAll:
-      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_all<true>, kBlock, all_lds_bytes(sc));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_all<false>, kBlock, all_lds_bytes(sc));
+    case kPaths:
+      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<true>, kBlock, paths_lds_bytes(sc));
+      else n = 0;
       break;
     case kShade:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
@@ -2698,10 +2812,8 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
 // levels: bounces per pass the caller asks for (1 or 2); returns how many the launched kernel performs — 2 only from
 // k_bounce (the large-scene kernels trace one depth per pass) — so that the host advances its depth loop by that much.
 // cnt_mid: fill-level row of depth + 1 (two bounces per pass: receives the ray count only), cnt_out: row of depth + levels.
-void launch_bounce_all(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret) {
-  const int bytes = all_lds_bytes(sc);
-  if (tables_in_lds(sc)) hipLaunchKernelGGL(k_bounce_all<true>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
-  else hipLaunchKernelGGL(k_bounce_all<false>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
+void launch_paths(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret) {
+  hipLaunchKernelGGL(k_paths<true>, dim3(grid), dim3(kBlock), paths_lds_bytes(sc), s, sc, b, qs, cnt, in, ret);
 }
 int launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, int levels, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
@@ -2819,7 +2931,7 @@ const KernelApi kApi = {
     "fast",
 #endif
     launch_generate, launch_primary, launch_bounce, launch_intersect, launch_shade, launch_collect, launch_count_stats,
-    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check, launch_bounce_all};
+    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check, launch_paths};
 
 }  // namespace
 }  // namespace PT_NS

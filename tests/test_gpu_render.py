@@ -175,10 +175,12 @@ def test_striped_tiles_compose(scene_dir):
     ((320, 200), dict(num_queues=32, unfused_primary=True, iters_per_batch=5)),
     ((320, 200), dict(debug_flags=1024)),                     # two bounces per pass: depths 1+2, 3+4, 5+6, 7
     ((320, 200), dict(debug_flags=1024, iters_per_batch=7, num_queues=16)),
-    ((320, 200), dict(debug_flags=4096)),                     # all depths >= 1 in one launch: persistent lanes with their own depth (k_bounce_all)
+    ((320, 200), dict(debug_flags=4096)),                     # one launch per depth (k_bounce) instead of all depths >= 1 in one launch (k_paths)
     ((640, 361), dict(debug_flags=4096, num_queues=8, iters_per_batch=3)),
     ((100, 7), dict(debug_flags=4096, num_queues=256)),       # most queues (and most waves' slices) are empty
     ((320, 200), dict(debug_flags=4096, num_queues=16, blocks_per_cu=1, iters_per_batch=40)),
+    ((320, 200), dict(blocks_per_cu=1, iters_per_batch=40)),  # k_paths: long slices per wave
+    ((320, 200), dict(blocks_per_cu=2, num_queues=128, iters_per_batch=2)),  # ... and slices shorter than a wave
     ((320, 200), dict(debug_flags=128)),                      # the one-group-at-a-time kernel with LDS tables (occupancy experiment)
     ((320, 201), dict(debug_flags=128, num_queues=32, iters_per_batch=6)),
 ])
@@ -195,14 +197,15 @@ def test_retirement_records_and_collect_layouts(scene_dir, res, kw):
     assert np.array_equal(bits(img), bits(ref)), kw
 
 
-@pytest.mark.parametrize("scene,res,depth", [("sphere", (200, 200), 4), ("stress", (160, 90), 8), ("cornell", (96, 64), 2), ("cornell", (96, 64), 13)])
+@pytest.mark.parametrize("scene,res,depth", [("sphere", (200, 200), 4), ("stress", (160, 90), 8), ("cornell", (96, 64), 2), ("cornell", (96, 64), 13), ("cornell", (96, 64), 17)])
 def test_all_depths_in_one_launch_on_other_scenes(scene_dir, scene, res, depth):
-    """k_bounce_all (debug_flags 4096) where the default tests do not take it: a scene with misses (sphere.txt: the sky factor
-    applied trace_depth - depth times, per lane), a scene whose tables stay in global memory (the 126-primitive stress scene),
-    the smallest depth (2: one bounce), and a depth beyond what its statistics rows cover (13: within 16, still taken)."""
+    """k_paths (all depths >= 1 in one launch) against the per-depth launches (debug_flags 4096) where the other tests do not
+    go: a scene with misses (sphere.txt: the sky factor applied trace_depth - depth times, per lane), a scene whose tables stay
+    in global memory (the 126-primitive stress scene), the smallest depth (2: one bounce), a depth beyond what its statistics
+    rows were first written for (13), and one beyond its limit (17: falls back to the per-depth launches)."""
     spp = 6
-    ref, rst = gpu_render(scene_dir[scene], res, spp, depth=depth)
-    img, st = gpu_render(scene_dir[scene], res, spp, depth=depth, debug_flags=4096)
+    ref, rst = gpu_render(scene_dir[scene], res, spp, depth=depth, debug_flags=4096)
+    img, st = gpu_render(scene_dir[scene], res, spp, depth=depth)
     assert list(st.live_rays[:depth]) == list(rst.live_rays[:depth])
     assert np.array_equal(bits(img), bits(ref))
 

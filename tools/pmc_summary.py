@@ -15,7 +15,7 @@ def load(d):
     return out
 
 def short(n):
-    for k in ("k_intersect_legacy", "k_intersect", "k_shade", "k_generate", "k_primary", "k_bounce", "k_gather", "k_count_stats"):
+    for k in ("k_intersect_legacy", "k_intersect", "k_shade", "k_generate", "k_primary", "k_paths", "k_bounce_all", "k_bounce", "k_gather", "k_collect", "k_count_stats"):
         if k in n:
             return k
     return None
