@@ -34,7 +34,6 @@ constexpr bool kAblateBuild = false;  // release library: pt_init rejects them
 
 std::string g_err;
 constexpr int kGridNodes = 1024;       // scenes from this many BVH nodes on are candidates for the uniform grid (build_grid, choose_traversal)
-constexpr int kBigKernelNodes = 2048;  // see tables(): scenes from this many BVH nodes on run depths >= 1 in k_bounce_big
 }  // namespace
 int pt_fail(const char* fmt, ...) {  // pt_internal.h: sets pt_last_error(), returns -1
   char buf[1024];
@@ -120,7 +119,7 @@ struct PtContext {
   bool fuse_primary = true, fuse_bounces = true;
   bool aa_jitter = false;
   bool has_triangles = false;  // SceneTables::has_triangles
-  int grid_primary = 0, grid_bounce = 0, grid_paths = 0;
+  int grid_primary = 0, grid_paths = 0;
   ptd::PathBuf buf[2]{};
   ptd::HitBuf hits{};
   ptd::RetireBuf ret{};  // retirement records + fill levels (pt_device.h)
@@ -526,13 +525,10 @@ ptk::SceneTables tables(const Ctx& g) {
   t.max_batch_iters = g.K;
   t.has_triangles = g.has_triangles ? 1 : 0;
   t.trace_depth = g.depth;
-  // k_bounce_big from kBigKernelNodes nodes on; debug_flags 64 / 128 force k_bounce<false> / k_bounce_big (A/B, same results)
-  t.big_kernel = (g.debug_flags & 64) ? 0 : ((g.debug_flags & 128) ? 1 : (g.num_nodes >= kBigKernelNodes ? 1 : 0));
-  // the grid walk lives in the big kernel; debug_flags 256 builds and uses it for any scene, 512 never (A/B, same results)
-  t.use_grid = g.have_grid && g.grid_enabled && !(g.debug_flags & 512) && !(g.debug_flags & 64) ? 1 : 0;
+  // debug_flags 256 builds and uses the grid for any scene, 512 never (A/B, same results)
+  t.use_grid = g.have_grid && g.grid_enabled && !(g.debug_flags & 512) ? 1 : 0;
   if (t.use_grid) {
-    t.big_kernel = 1;
-    t.lds_table_bytes = -1;  // (a forced grid on a small scene: the big kernel reads the tables from memory)
+    t.lds_table_bytes = -1;  // (a forced grid on a small scene: the grid kernels read the tables from memory)
     t.grid_start = g.d_grid_start + g.grid_guard;
     t.grid_items = g.d_grid_items;
     for (int a = 0; a < 3; ++a)
@@ -573,6 +569,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   b.slot_shift = g.slot_shift;
   b.aa_jitter = g.aa_jitter ? 1 : 0;
   b.debug = kAblateBuild ? g.debug_flags : 0;
+  b.flat = g.fuse_bounces ? 0 : 1;
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;
   b.inv_stripe = g.stripe ? 1.0f / (float)g.stripe : 0.0f;
@@ -588,12 +585,8 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   } else {
     k.generate(g.stream, g.grid_gen, g.dcam, b, queues_for(g, g.grid_gen), g.buf[0], g.d_cnt);
   }
-  // debug_flags 1024: two bounces per pass in the fused bounce kernel of the small scenes (same image; measured 4-5 %
-  // slower than one per pass, DESIGN.md section 5, so not the default): the input alternates between the two path buffers
-  // per LAUNCH, not per depth
   int src = d0 & 1;
-  // Depths >= 1 of the LDS-table scenes: ONE launch of k_paths — persistent lanes with their own depth, no path state through
-  // HBM after depth 0 (plan_launch decides: grid_paths > 0; debug_flags 4096 keeps the per-depth k_bounce launches, same image)
+  // Depths >= 1, fused: ONE launch of k_paths — persistent lanes with their own depth, no path state through HBM after depth 0
   const bool all_depths = g.grid_paths > 0;
   if (all_depths) {
     EventPair ev{};
@@ -607,29 +600,21 @@ int run_batch(Ctx& g, int iter_first, int kb) {
       g.pending_isect.push_back(ev);
     }
   }
-  for (int d = d0; d < g.depth && !all_depths;) {
+  // ... unfused (tests, A/B): computeIntersections and shadeAndExtendRays as separate launches per depth
+  for (int d = d0; d < g.depth && !all_depths; ++d) {
     const int32_t* cin = g.d_cnt + per_depth * d;
-    int32_t* cmid = g.d_cnt + per_depth * (d + 1);
+    int32_t* cout = g.d_cnt + per_depth * (d + 1);
     EventPair ev{};
     if (g.time_kernels) {  // brackets the dominant kernel of this depth
       if (get_events(g, &ev)) return -1;
       HIP_OK(hipEventRecord(ev.a, g.stream));
     }
-    int covered = 1;
-    if (g.fuse_bounces) {
-      const int want = ((g.debug_flags & 1024) && d + 2 <= g.depth) ? 2 : 1;
-      int32_t* cout = g.d_cnt + per_depth * std::min(d + 2, g.depth);
-      covered = k.bounce(g.stream, g.grid_bounce, sc, b, d, want, queues_for(g, g.grid_bounce), cin, cmid, cout, g.buf[src], g.buf[src ^ 1], g.ret);
-    } else {
-      k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[src], g.hits, g.legacy, d == 0);
-    }
+    k.intersect(g.stream, g.grid_isect, sc, queues_for(g, g.grid_isect), cin, g.buf[src], g.hits, g.legacy, d == 0);
     if (g.time_kernels) {
       HIP_OK(hipEventRecord(ev.b, g.stream));
       g.pending_isect.push_back(ev);
     }
-    if (!g.fuse_bounces)
-      k.shade(g.stream, g.grid_shade, sc, b, d, queues_for(g, g.grid_shade), cin, cmid, g.buf[src], g.hits, g.buf[src ^ 1], g.ret);
-    d += covered;
+    k.shade(g.stream, g.grid_shade, sc, b, d, queues_for(g, g.grid_shade), cin, cout, g.buf[src], g.hits, g.buf[src ^ 1], g.ret);
     src ^= 1;
   }
   if (getenv("PT_DUMP_QUEUE_BALANCE")) {  // diagnostics: fill levels of the queues per depth (before k_count_stats zeroes them)
@@ -665,10 +650,7 @@ void plan_launch(Ctx& g) {
   g.grid_isect = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
   g.grid_shade = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kShade, t));
   g.grid_primary = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
-  g.grid_bounce = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kBounce, t));
-  // (k_paths' per-depth statistics cover depths 1..15)
-  const bool paths = g.fuse_primary && g.fuse_bounces && !(g.debug_flags & 4096) && t.lds_table_bytes >= 0 && !t.big_kernel && g.depth > 1 && g.depth <= 16;
-  g.grid_paths = paths ? g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPaths, t)) : 0;
+  g.grid_paths = (g.fuse_bounces && g.depth > 1) ? g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPaths, t)) : 0;
 }
 
 // Make candidate i the grid the kernels walk.
@@ -696,7 +678,7 @@ int choose_traversal(Ctx& g) {
     }
     g.grid_alts.clear();
   };
-  if (!g.have_grid || !g.fuse_bounces || (g.debug_flags & (256 | 512 | 64))) {
+  if (!g.have_grid || !g.fuse_bounces || (g.debug_flags & (256 | 512))) {
     if (g.have_grid) drop_unused_grids(0);
     return 0;
   }
@@ -850,11 +832,8 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
     while ((chunks + Q - 1) / Q > 128 && 2 * Q <= cu_waves && cu_waves % (2 * Q) == 0) Q *= 2;
   const int nq = (int)((chunks + Q - 1) / Q);
   const int grid = g.num_cus * 8;
-  // Retirement records: one private segment per (queue, iteration of the batch, wave of the queue), each able to hold all
-  // of the queue's pixels (pt_device.h RetireBuf): samples * R * 16 bytes.  HBM is there to be used (288 GB), but keep the
-  // default batch within ~48 GB of records.
-  const int R = std::max(1, grid * ptk::kWavesPerBlock / Q);
-  while (K > 1 && (int64_t)K * Q * nq * 64 * R * 16 > (48ll << 30)) --K;
+  // Retirement records: one slot per (iteration of the batch, pixel) — regions (queue, iteration) of nq * 64 slots, exactly
+  // full at the end of a batch (pt_device.h RetireBuf): 16 bytes per sample and batch.
   g.K = K;
   g.grid = grid;
   g.qs.Q = Q;
@@ -865,7 +844,6 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   g.qs.cap = K * nq * 64;
   g.stride = (int64_t)Q * g.qs.cap;
   g.ret.seg_cap = nq * 64;
-  g.ret.R = R;
   g.ret.kmax = K;
 
   // scene tables
@@ -983,9 +961,9 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   if (alloc_pathbuf(g, &g.buf[0], g.stride) || alloc_pathbuf(g, &g.buf[1], g.stride)) return -1;
   if (!g.fuse_bounces && alloc_hitbuf(g, &g.hits, g.stride)) return -1;  // hit records reach HBM only in the unfused form
   {
-    const size_t segs = (size_t)Q * g.ret.R * g.ret.kmax;
-    if (dalloc(g, &g.ret.rec, segs * g.ret.seg_cap) || dalloc(g, &g.ret.cnt, segs)) return -1;
-    HIP_OK(hipMemset(g.ret.cnt, 0, segs * sizeof(int32_t)));  // k_collect re-zeroes what it consumed after every batch
+    const size_t regions = (size_t)Q * g.ret.kmax;
+    if (dalloc(g, &g.ret.rec, regions * g.ret.seg_cap) || dalloc(g, &g.ret.cnt, regions)) return -1;
+    HIP_OK(hipMemset(g.ret.cnt, 0, regions * sizeof(unsigned long long)));  // k_collect re-zeroes them after every batch
   }
   if (dalloc(g, &g.d_image, 3 * (size_t)g.N)) return -1;
   if (dalloc(g, &g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;
@@ -1251,7 +1229,7 @@ int pt_ctx_get_stats(PtContext* c, PtStats* out) {
   out->intersect_ms = g.isect_ms;
   out->render_ms = g.render_ms;
   out->num_cus = g.num_cus;
-  out->grid_blocks = g.grid_paths > 0 ? g.grid_paths : (g.fuse_bounces ? g.grid_bounce : g.grid_isect);
+  out->grid_blocks = g.grid_paths > 0 ? g.grid_paths : g.grid_isect;
   out->num_queues = g.qs.Q;
   out->iters_per_batch = g.K;
   out->device_bytes = g.device_bytes;

@@ -79,16 +79,11 @@ struct Camera {
 //   plane 0   origin.xyz, direction.x
 //   plane 1   direction.yz, colour.xy
 //   plane 2   colour.z | sample id inside the batch: k << slot_shift | tile pixel (BatchInfo::slot_shift), 8 B per path
-// 40 B per path, the algorithmic minimum of SURVEY §8(d) (+ 0: the id replaces the reference's pixelIndex).  -DPT_REC_TAGGED
-// widens plane 2 to 16 B with utilhash(global pixel index) and k carried along (saves a hash and a shift per bounce; measured
-// 10-20 % SLOWER — the bounce kernel's time follows its bytes — so it is not the default).
+// 40 B per path, the algorithmic minimum of SURVEY §8(d) (+ 0: the id replaces the reference's pixelIndex).
 struct alignas(16) Word4 {
   float x, y, z, w;
 };
-#ifndef PT_REC_TAGGED
-#define PT_REC_TAGGED 0
-#endif
-constexpr int kPathPlane2Bytes = PT_REC_TAGGED ? 16 : 8;  // plane 2 without the carried hash / iteration: colour.z, slot
+constexpr int kPathPlane2Bytes = 8;  // plane 2: colour.z, sample id
 struct PathBuf {
   Word4* r;        // planes 0 and 1 at r, r + stride; plane 2 (kPathPlane2Bytes per path) at r + 2 * stride
   int64_t stride;  // paths per plane
@@ -102,25 +97,29 @@ struct HitBuf {
   int64_t stride;
 };
 
-// Retirement records.  A sample's final colour is known when its path dies — at any depth, in whatever order compaction
-// has left the paths in — while finalGather (pathtrace.cu:439-444) needs, per pixel, the colours of its K samples in
-// iteration order.  Rounds 1-2 stored each colour at final[k*N + p]: one scattered 16-byte write per sample, each a
-// partially written DRAM line — a third of the bounce kernel's time at K = 25 (round 3 ablation).  Now:
-//   * a queue owns the SAME pixel chunks in every iteration (Queues, below), i.e. a fixed set of nq*64 pixels;
-//   * a retiring lane appends the record (r, g, b, tile pixel index) to a segment that belongs to (queue q, iteration k,
-//     wave r of the queue's waves) alone — consecutive lanes to consecutive addresses, no atomics: the segment's fill
-//     level is a counter private to that wave (kept in LDS during a kernel, in `cnt` between kernels);
-//   * k_collect, one workgroup per queue, reads the segments of (q, k) for k = 0, 1, ... (coalesced), drops the colours
-//     into an LDS tile indexed by pixel, and adds the tile to the queue's pixels — the reference's summation order.
-// Every sample retires exactly once, so segment (q, k, *) fill levels add up to the queue's pixel count; a segment can
-// hold all of them (seg_cap = nq * 64).
+// Retirement records.  A sample's final colour is known when its path dies — at any depth, in whatever order the lanes
+// happen to finish — while finalGather (pathtrace.cu:439-444) needs, per pixel, the colours of its K samples in iteration
+// order.  Rounds 1-2 stored each colour at final[k*N + p]: one scattered 16-byte write per sample, each a partially written
+// DRAM line — a third of the bounce kernel's time at K = 25 (round 3 ablation).  Round 3 appended records to segments private
+// to (queue, iteration, wave), each sized for ALL of the queue's pixels: coalesced, but 32 x over-provisioned (27 GB for a
+// 1080p frame).  Now the fit is exact:
+//   * a queue owns the SAME pixel chunks in every iteration (Queues, below): region (q, k) has one record slot per pixel of
+//     queue q, seg_cap = nq * 64 of them, and every sample of (q, k) retires exactly once, so the region ends up exactly full;
+//   * depth 0 (k_primary) appends its retirees at the FRONT of region (q, k) and its survivors to the depth-1 list (q, k) — list
+//     (q, k) lives at path index q * cap + k * seg_cap — with ONE 64-bit atomic per 64-sample group on cnt[q][k]
+//     (high word: records appended, low word: survivors appended);
+//   * depths >= 1 (k_paths) run after depth 0 of the whole batch: the survivor counts n_k are final, a wave takes a
+//     contiguous slice [lo, hi) of the queue's concatenated lists and retires exactly the paths it took, so its records
+//     of iteration k go to region (q, k) at (pixels - n_k) + |[0, lo) ∩ list k| onward — consecutive lanes to consecutive
+//     addresses, no global atomics, the positions come from a counter in LDS;
+//   * k_collect, one workgroup per queue, reads region (q, k) for k = 0, 1, ... front to back, drops the colours into an LDS
+//     tile indexed by pixel, and adds the tile to the queue's pixels — the reference's summation order.
+// The unfused stage kernels (tests, A/B) append every record at the front through the high word, one atomic per record.
 struct RetireBuf {
-  Word4* rec;       // [Q][R][kmax][seg_cap]
-  int32_t* cnt;     // [Q][R][kmax] fill levels (zero between batches: k_collect resets what it consumed)
-  int32_t seg_cap;  // nq * 64: pixels a queue owns
-  int32_t R;        // waves per queue the segments are provisioned for (>= W / Q of every launch)
-  int32_t kmax;     // iterations per batch the segments are provisioned for
-  int32_t pad;
+  Word4* rec;               // [Q][kmax][seg_cap]
+  unsigned long long* cnt;  // [Q][kmax]: records appended at the front << 32 | depth-0 survivors appended to list (q, k); zero between batches
+  int32_t seg_cap;          // nq * 64: pixels a queue owns (a multiple of 64)
+  int32_t kmax;             // iterations per batch the regions are provisioned for
 };
 
 // Work distribution.  Paths live in Q independent queues of capacity `cap`

@@ -38,11 +38,8 @@ struct SceneTables {
   // Iterations per wavefront batch of the context (>= every BatchInfo::K it launches): sizes the per-iteration RNG hash
   // table in LDS (none beyond 256 iterations, those batches hash per ray).
   int32_t max_batch_iters;
-  // Host-side choice of the depth >= 1 kernel for scenes whose tables are not in LDS: 1 = k_bounce_big (one group at a
-  // time per wave, 6 waves per SIMD: scenes with deep subtrees, bound by the latency of the per-lane scans), 0 = k_bounce<false>.
-  int32_t big_kernel;
-  // Uniform grid over the leaf boxes (pt_api.cpp build_grid; grid_search in pt_kernels.hip): the depth >= 1 kernel of large
-  // scenes walks it instead of the BVH when that is faster (measured by the host at init).  A cell lists every leaf whose box,
+  // Uniform grid over the leaf boxes (pt_api.cpp build_grid; grid_search in pt_kernels.hip): the fused kernels of large
+  // scenes walk it instead of the BVH when that is faster (measured by the host at init).  A cell lists every leaf whose box,
   // grown by grid_pad, overlaps it: cell c's records are grid_items[grid_start[c] .. grid_start[c + 1]), each a ptd::Node
   // with the leaf's box, `skip` = the leaf's threaded node index and `geom` = geom index << 8 | primitive type << 6 | bit a
   // set when the leaf is also listed in the neighbour cell a (0..5 = -x, +x, -y, +y, -z, +z).  A leaf is a candidate exactly when the ray passes its own box
@@ -69,6 +66,8 @@ struct BatchInfo {
   int32_t trace_depth;
   int32_t slot_shift;  // sample id of a path = k << slot_shift | tile pixel; 2^slot_shift >= N, k < 2^(31 - slot_shift)
   int32_t aa_jitter;  // 1: stochastic anti-aliasing of the camera rays (extension, PtOptions.aa_jitter)
+  int32_t flat;   // 1: depth 0 appends its survivors to ONE dense depth-1 list per queue (the unfused k_intersect / k_shade pair
+                  // reads that); 0: to one list per (queue, iteration) (k_paths, pt_device.h RetireBuf)
   int32_t debug;  // profiling ablations (wrong results; honoured only by -DPT_ABLATE builds): 4 = skip primitive tests,
                   // 8 = skip shade_bounce
 };
@@ -76,7 +75,7 @@ struct BatchInfo {
 // Resident workgroups per CU for each persistent kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor),
 // so that grid = CUs * blocks never exceeds what is co-resident: work is dealt statically to waves,
 // a workgroup that has to wait for a free slot would run its whole share after everybody else.
-enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kBounce = 5, kPaths = 6 };
+enum KernelId { kGenerate = 0, kIntersect = 1, kShade = 2, kIntersectLegacy = 3, kPrimary = 4, kPaths = 5 };
 
 // pt_kernels.hip is compiled once per arithmetic mode (PtOptions.arith, include/pt_amd.h):
 //   0 exact  -ffp-contract=off, every operation in the reference's order: bit-identical to oracle/pt_oracle.cpp
@@ -93,16 +92,11 @@ struct KernelApi {
   // Also writes the queue fill counts cnt0[q*cnt_stride].
   void (*generate)(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
                    ptd::PathBuf out, int32_t* cnt0);
-  // Depth 0 fused (generate + intersect + shade + compaction): survivors go to `out` / cnt_out (the depth-1
-  // queues), retired samples to the retirement records `ret`; cnt0 receives the per-queue sample counts (statistics only).
+  // Depth 0 fused (generate + intersect + shade + compaction): survivors go to `out` — one depth-1 list per (queue, iteration),
+  // counted in `ret` (BatchInfo::flat: one list per queue, counted in cnt_out) — retired samples to the retirement records `ret`;
+  // cnt0 receives the per-queue sample counts (statistics only).
   void (*primary)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                   const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf ret);
-  // Depth >= 1 fused (intersect + shade + compaction), hit records stay on chip.  levels = 2 asks for two bounces per pass
-  // (the survivors of the input queue's groups are traced once more from registers, pt_kernels.hip RegGroup): the return
-  // value says how many depths the launch covered (2 only from the small-scene kernel).  cnt_mid = fill-level row of
-  // depth + 1 (receives ray counts only when two depths are covered), cnt_out = row of depth + 2.
-  int (*bounce)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, int levels, const ptd::Queues& qs,
-                const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret);
   // computeIntersections over the live paths of every queue.  exact_arith: these are primary rays (depth 0), which
   // are traced with the reference's exact arithmetic in every mode (pt_kernels.hip, namespace ex).
   void (*intersect)(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,

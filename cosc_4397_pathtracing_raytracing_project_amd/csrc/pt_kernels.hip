@@ -13,11 +13,11 @@
 //                into the image in iteration order)
 //   k_preview    sendImageToPBO          src/pathtrace.cu:250-268
 //   k_save_u8    saveImage + savePNG     src/main.cpp:86-107, src/image.cpp:22-39
-// and the two kernels the default pipeline actually runs, which fuse the above per depth so that
-// neither the primary ray nor the hit record ever goes through HBM:
-//   k_primary    depth 0:  generate + intersect + shade + compaction
-//   k_bounce     depth >= 1: intersect + shade + compaction, candidate ring carried across groups
-//   k_bounce_big the same for scenes whose tables do not fit LDS: uniform grid walk (grid_search) or BVH scan
+// and the two kernels the default pipeline actually runs, which fuse the above so that neither the primary ray nor the
+// hit record ever goes through HBM, and no path state after depth 0:
+//   k_primary    depth 0:  generate + intersect + shade + compaction into one depth-1 list per (queue, iteration)
+//   k_paths      ALL depths >= 1 in one launch: persistent lanes with their own depth, a dead lane takes the next
+//                depth-1 ray; three search forms (LDS tables / top list + subtree scans / uniform grid walk)
 // (k_generate / k_intersect / k_shade remain as the unfused form for stage-parity tests and A/B runs,
 // k_intersect_legacy as the per-lane tree walk the wave-cooperative search replaced.)
 //
@@ -131,16 +131,11 @@ PT_DEV int wave_max_stat(int v) {
 #define PT_STEAL_MIN 16
 #endif
 constexpr int kStealMin = PT_STEAL_MIN;  // idle lanes needed before a work-stealing step is run (65: never)
-// Waves per SIMD the fused kernels are compiled for (__launch_bounds__ second argument).  5 would cap them at 96 VGPRs
-// (1-5 spilled) and, with the trimmed per-wave LDS block, fit a fifth workgroup per CU for cornell-sized scenes; measured
-// in-box (tools/build_variant.sh + tools/ab_libs.sh): k_bounce 322 -> 351 us (fast), 363 -> 422 us (exact).  So 4.
-#ifndef PT_BOUNCE_WAVES
-#define PT_BOUNCE_WAVES 4
-#endif
+// Waves per SIMD the depth-0 kernel is compiled for (__launch_bounds__ second argument).
 #ifndef PT_PRIMARY_WAVES
 #define PT_PRIMARY_WAVES 4
 #endif
-constexpr int kBounceWaves = PT_BOUNCE_WAVES, kPrimaryWaves = PT_PRIMARY_WAVES;
+constexpr int kPrimaryWaves = PT_PRIMARY_WAVES;
 
 struct f3 {
   float x, y, z;
@@ -397,18 +392,13 @@ PT_DEV int global_pixel(const BatchInfo& b, int p) {
 }
 
 // ───────────────────────────── path records (ptd::PathBuf) ─────────────────
-// What rides along with a path besides its ray and colour: the sample id and — PT_REC_TAGGED builds only — the per-pixel
-// half of the RNG seed and the iteration inside the batch (so that no depth has to divide the sample id or hash the pixel
-// index again: -56 VALU per 64-ray group, +8 B per path each way).
-#ifndef PT_REC_TAGGED
-#define PT_REC_TAGGED 0
-#endif
-constexpr bool kTagged = PT_REC_TAGGED != 0;
-static_assert(kTagged == (ptd::kPathPlane2Bytes == 16), "pt_device.h and PT_REC_TAGGED disagree about plane 2");
+// What rides along with a path besides its ray and colour: the sample id.  (phash / k: the per-pixel half of the RNG seed and the
+// iteration inside the batch, kept in registers by the kernels that have them; they are not part of the record in memory — a
+// round-3 build that carried them, 48 B per path, saved 56 VALU per 64-ray group and was 10-20 % slower.)
 struct PathTag {
   int slot;
-  uint32_t phash;  // utilhash(global pixel index)                                   (kTagged)
-  int k;           // iteration inside the batch: iteration = BatchInfo::iter_first + k   (kTagged)
+  uint32_t phash;  // utilhash(global pixel index)
+  int k;           // iteration inside the batch: iteration = BatchInfo::iter_first + k
 };
 struct PathRec {
   f3 o, d, c;
@@ -417,21 +407,14 @@ struct PathRec {
 struct alignas(8) Word2 {
   float x, y;
 };
-// plane 2: colour.z, slot [, pixel hash, k]
+// plane 2: colour.z, slot
 PT_DEV void plane2_load(const ptd::PathBuf& b, int64_t at, float& cz, PathTag& tag) {
-  if constexpr (kTagged) {
-    const ptd::Word4 w2 = b.r[2 * b.stride + at];
-    cz = w2.x;
-    tag.slot = __float_as_int(w2.y), tag.phash = __float_as_uint(w2.z), tag.k = __float_as_int(w2.w);
-  } else {
-    const Word2 w2 = reinterpret_cast<const Word2*>(b.r + 2 * b.stride)[at];
-    cz = w2.x;
-    tag.slot = __float_as_int(w2.y), tag.phash = 0u, tag.k = 0;
-  }
+  const Word2 w2 = reinterpret_cast<const Word2*>(b.r + 2 * b.stride)[at];
+  cz = w2.x;
+  tag.slot = __float_as_int(w2.y), tag.phash = 0u, tag.k = 0;
 }
 PT_DEV void plane2_store(const ptd::PathBuf& b, int64_t at, float cz, const PathTag& tag) {
-  if constexpr (kTagged) b.r[2 * b.stride + at] = ptd::Word4{cz, __int_as_float(tag.slot), __uint_as_float(tag.phash), __int_as_float(tag.k)};
-  else reinterpret_cast<Word2*>(b.r + 2 * b.stride)[at] = Word2{cz, __int_as_float(tag.slot)};
+  reinterpret_cast<Word2*>(b.r + 2 * b.stride)[at] = Word2{cz, __int_as_float(tag.slot)};
 }
 PT_DEV void path_load_ray(const ptd::PathBuf& b, int64_t at, f3& o, f3& d) {  // planes 0, 1
   const ptd::Word4 w0 = b.r[at], w1 = b.r[b.stride + at];
@@ -468,48 +451,35 @@ PT_DEV void sample_of(const PathTag& tag, const BatchInfo& b, int& k, int& pl) {
   pl = tag.slot & ((1 << b.slot_shift) - 1);
 }
 // makeSeededRandomEngine's seed (pathtrace.cu:205) of a path at `depth`: utilhash((1 << 31) | depth << 22 | iteration) ^
-// utilhash(global pixel index).  The first factor comes from the per-block table (iter_hash_of); the second rides along
-// with the path (kTagged) or is recomputed from the tile pixel.
-PT_DEV uint32_t path_seed(const PathTag& tag, int k, int pl, const uint32_t* ihash, const SceneTables& sc, const BatchInfo& b, int depth) {
-  const uint32_t ph = kTagged ? tag.phash : utilhash((uint32_t)global_pixel(b, pl));
-  return iter_hash_of(ihash, sc, b, depth, k) ^ ph;
+// utilhash(global pixel index).  The first factor comes from the per-block table (iter_hash_of).
+PT_DEV uint32_t path_seed(int k, int pl, const uint32_t* ihash, const SceneTables& sc, const BatchInfo& b, int depth) {
+  return iter_hash_of(ihash, sc, b, depth, k) ^ utilhash((uint32_t)global_pixel(b, pl));
 }
 
 // ───────────────────────────── retirement records (ptd::RetireBuf) ─────────
-// Per-wave state: the wave's own segments (queue q, iteration k, wave r of the queue) and their fill levels, which live
-// in LDS while the kernel runs (loaded by retire_begin, written back by retire_end: nobody else touches them).
+// One queue's regions and counters (pt_device.h RetireBuf).
 struct Retire {
-  ptd::Word4* seg;  // records of segment (q, 0, r); segment (q, k, r) starts k * seg_cap records further
-  int* fill;        // LDS [K]: fill levels of the wave's segments
+  ptd::Word4* rec;          // region (q, 0); region (q, k) starts k * seg_cap records further
+  unsigned long long* cnt;  // [kmax]: records appended at the front << 32 | depth-0 survivors in list (q, k)
   int seg_cap;
 };
-__host__ __device__ inline int retire_wave_bytes(const SceneTables& sc) { return (sc.max_batch_iters * 4 + 15) & ~15; }
-__host__ __device__ inline int retire_lds_bytes(const SceneTables& sc) { return kWavesPerBlock * retire_wave_bytes(sc); }
-PT_DEV Retire retire_begin(void* lds_base, const ptd::RetireBuf& rb, const SceneTables& sc, const BatchInfo& b, int q, int r, int wib, int lane) {
+PT_DEV Retire retire_of(const ptd::RetireBuf& rb, int q) {
   Retire rt;
-  rt.fill = reinterpret_cast<int*>(reinterpret_cast<char*>(lds_base) + wib * retire_wave_bytes(sc));
-  const int64_t s0 = ((int64_t)q * rb.R + r) * rb.kmax;
-  rt.seg = rb.rec + s0 * rb.seg_cap;
+  rt.rec = rb.rec + (int64_t)q * rb.kmax * rb.seg_cap;
+  rt.cnt = rb.cnt + (int64_t)q * rb.kmax;
   rt.seg_cap = rb.seg_cap;
-  for (int k = lane; k < b.K; k += 64) rt.fill[k] = rb.cnt[s0 + k];
   return rt;
 }
-PT_DEV void retire_end(const Retire& rt, const ptd::RetireBuf& rb, const BatchInfo& b, int q, int r, int lane) {
-  const int64_t s0 = ((int64_t)q * rb.R + r) * rb.kmax;
-  for (int k = lane; k < b.K; k += 64) rb.cnt[s0 + k] = rt.fill[k];
-}
-// The lanes with `dead` append (colour, tile pixel index) to the wave's segment of their iteration k.  The position comes
-// from ONE returning LDS atomic on the segment's fill level, issued by all dead lanes at once: lanes of the same iteration
-// get consecutive records (stores of a group's retirees stay contiguous runs), and a group whose dead lanes belong to
-// several iterations — the rule at the deep depths, where a queue's iteration-major order has been shuffled by seven
-// compactions and every remaining path retires — costs no more than one whose lanes agree.  (First version: a loop over
-// the distinct iterations with ballot / rank / a cached fill level; PMC: +135 VALU and +180 SALU per group at depth 7.)
-PT_DEV int retire_reserve(const Retire& rt, bool dead, int k) { return dead ? atomicAdd(&rt.fill[k], 1) : 0; }
 PT_DEV void retire_store(const Retire& rt, bool dead, int k, int pos, int pl, f3 c) {
 #ifdef PT_ABL_NO_RETIRE  // timing experiment only (wrong images)
   return;
 #endif
-  if (dead) rt.seg[(int64_t)k * rt.seg_cap + pos] = ptd::Word4{c.x, c.y, c.z, __int_as_float(pl)};
+  if (dead) rt.rec[(int64_t)k * rt.seg_cap + pos] = ptd::Word4{c.x, c.y, c.z, __int_as_float(pl)};
+}
+// The unfused stage kernels: every record appended at the front of its region, one returning atomic per record on the
+// region's counter (test / A-B form; the fused kernels take one atomic per 64 samples or none at all).
+PT_DEV void retire_append(const Retire& rt, bool dead, int k, int pl, f3 c) {
+  if (dead) retire_store(rt, true, k, (int)(atomicAdd(&rt.cnt[k], 1ull << 32) >> 32), pl, c);
 }
 // Queue q's share of an iteration (ptd::Queues): chunks q, q + Q, ... of the tile's ceil(N / 64); only the tile's last
 // chunk can be partial, and it is the last chunk of the queue that owns it.
@@ -1119,42 +1089,36 @@ PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
   s.d = perturb ? pert : refl;
 }
 
-// Retirement + wave-level compaction shared by k_shade and k_primary.
-//   1. dead lanes write their final colour (exactly one write per (iteration, pixel));
-//   2. ballot + popcount, lane 0 reserves room in the queue with ONE atomic per wave — issued here,
-//      before shade_bounce, so its round trip hides behind the trigonometry;
-//   3. caller runs shade_bounce, then emit_survivors stores the compacted paths.
+// __ballot() of the HIP headers goes through an integer compare (v_cndmask 0 / 1 + v_cmp per call when the predicate already
+// sits in a scalar register pair); the builtin takes the predicate as it is.
+PT_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+PT_DEV int rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); }
+
+// Retirement + wave-level compaction of depth 0 (k_primary): a group = 64 pixels of ONE iteration k of queue q.
+//   1. ballots of survivors and retirees; lane 0 reserves room for both with ONE returning 64-bit atomic on cnt[q][k]
+//      (records << 32 | survivors) — issued before shade_bounce, the stores follow one loop iteration later (Deferred);
+//   2. survivors go to list (q, k) (path index q * cap + k * seg_cap + ...), records to the front of region (q, k).
+// flat (BatchInfo::flat: the consumer is the unfused k_intersect / k_shade pair, which wants ONE dense list per queue): the
+// survivors' position comes from the queue's depth-1 counter instead (a second atomic), the records go the same way.
 struct Reservation {
-  unsigned long long live;
-  int base;
-  int rpos;  // dead lanes: the lane's record position in its retirement segment
+  unsigned long long live, dead;
+  unsigned long long base;  // lane 0: record position << 32 | survivor position of the group's first
 };
-// DEFER_RETIRE: the retirement records are stored by flush_deferred one loop iteration later, together with the survivors
-// (fused kernels: every store of an iteration is then issued right after the iteration's one vector-memory wait and has a
-// whole iteration to be acknowledged before the next — vmcnt counts stores too).
-template <bool DEFER_RETIRE = false>
-PT_DEV Reservation retire_and_reserve(bool valid, const ShadeIO& s, int k, int pl, const Retire& rt, int32_t* __restrict__ counter, int lane) {
-  // dead lanes: one 16-byte record each, appended to the wave's own segment of iteration k (retire_reserve / retire_store)
-  // — rounds 1-2 scattered them over final[k * N + p], a partial DRAM line per sample
+PT_DEV Reservation reserve_group(bool alive, bool dead, unsigned long long* cnt_k, int32_t* flat_counter, bool flat, int lane) {
   Reservation r;
-  r.rpos = retire_reserve(rt, valid && !s.alive, k);
-  if (!DEFER_RETIRE) retire_store(rt, valid && !s.alive, k, r.rpos, pl, s.c);
-  r.live = __ballot(valid && s.alive);
-  r.base = 0;
-  if (r.live && lane == 0) r.base = atomicAdd(counter, __popcll(r.live));
+  r.live = ballot(alive), r.dead = ballot(dead);
+  r.base = 0ull;
+  if (lane == 0 && (r.live | r.dead)) {
+    const unsigned long long nl = (unsigned long long)__popcll(r.live), nd = (unsigned long long)__popcll(r.dead);
+    unsigned long long old = atomicAdd(cnt_k, (nd << 32) | (flat ? 0ull : nl));
+    if (flat && nl) old = (old & 0xffffffff00000000ull) | (uint32_t)atomicAdd(flat_counter, (int)nl);
+    r.base = old;
+  }
   return r;
 }
-PT_DEV void emit_survivors(const Reservation& r, bool alive, const ShadeIO& s, const PathTag& tag, int64_t qbase, ptd::PathBuf out) {
-  if (r.live) {
-    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(r.live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)r.live, 0));
-    const int base = __builtin_amdgcn_readfirstlane(r.base);
-    if (alive) path_store(out, qbase + base + rank, s.o, s.d, s.c, tag);
-  }
-}
-
-// Deferred emission (fused kernels).  The reservation is a RETURNING global atomic: ~2-3 thousand cycles round trip,
-// far more than the direction sampling it used to hide behind (fast mode: ~70 instructions).  The survivors of a
-// shaded group therefore wait in registers until the NEXT group's candidate search has run, and are stored then.
+// Deferred emission.  The reservation is a RETURNING global atomic: ~2-3 thousand cycles round trip, far more than the
+// direction sampling it used to hide behind.  The survivors and records of a shaded group therefore wait in registers until
+// the NEXT group's candidate search has run, and are stored then.
 struct Deferred {
   Reservation res;
   ShadeIO s;
@@ -1164,10 +1128,11 @@ struct Deferred {
 };
 PT_DEV void flush_deferred(Deferred& df, int64_t qbase, ptd::PathBuf out, const Retire& rt, const BatchInfo& b) {
   if (df.any) {
-    emit_survivors(df.res, df.alive, df.s, df.tag, qbase, out);
-    int k, pl;
-    sample_of(df.tag, b, k, pl);
-    retire_store(rt, df.dead, k, df.res.rpos, pl, df.s.c);
+    const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)df.res.base);
+    const uint32_t db = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(df.res.base >> 32));
+    const int64_t list = b.flat ? qbase : qbase + (int64_t)df.tag.k * rt.seg_cap;
+    if (df.alive) path_store(out, list + lb + rank_in(df.res.live), df.s.o, df.s.d, df.s.c, df.tag);
+    retire_store(rt, df.dead, df.tag.k, (int)db + rank_in(df.res.dead), df.tag.slot & ((1 << b.slot_shift) - 1), df.s.c);
   }
   df.any = false;
 }
@@ -1177,7 +1142,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
                                                   ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
                                                   ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // [retirement fill levels][materials][iteration hashes]
+  char* lds = reinterpret_cast<char*>(lds_raw);  // [materials][iteration hashes]
   stage16(lds, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
   uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + ((sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15));
   iter_hash_fill(ihash, sc, b, depth);
@@ -1187,7 +1152,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
   const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, threadIdx.x >> 6, lane);
+  const Retire rt = retire_of(ret, q);
   const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
   const int64_t HS = hits.stride;
   const int64_t qbase = (int64_t)q * qs.cap;
@@ -1225,13 +1190,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
     bo.kind = 0;
     int k, pl;
     sample_of(cur.tag, b, k, pl);
-    if (valid) bo = shade_decide(mats, b.trace_depth, depth, path_seed(cur.tag, k, pl, ihash, sc, b, depth), cur.ht, cur.hmat, s);
-    const Reservation res = retire_and_reserve(valid, s, k, pl, rt, &cnt_out[(size_t)q * qs.cnt_stride], lane);
+    if (valid) bo = shade_decide(mats, b.trace_depth, depth, path_seed(k, pl, ihash, sc, b, depth), cur.ht, cur.hmat, s);
+    // dead lanes: one record each at the front of region (q, k); survivors: ballot + popcount, ONE atomic per wave on the
+    // queue's counter of the next depth, compacted stores
+    retire_append(rt, valid && !s.alive, k, pl, s.c);
     const bool alive = valid && s.alive;
+    const unsigned long long live = ballot(alive);
+    int base = 0;
+    if (live && lane == 0) base = atomicAdd(&cnt_out[(size_t)q * qs.cnt_stride], (int)__popcll(live));
     if (alive) shade_bounce(bo, cur.hn, cur.hp, s);
-    emit_survivors(res, alive, s, cur.tag, qbase, out);
+    if (live) {
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (alive) path_store(out, qbase + base + rank_in(live), s.o, s.d, s.c, cur.tag);
+    }
   }
-  retire_end(rt, ret, b, q, r, lane);
 }
 
 // ── candidate ring with carry-over (fused kernels) ────────────────────────────────────────
@@ -1674,82 +1646,6 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
   while (cr.count > 0) grid_filter<NPAR, EX>(c, cr, min(64, cr.count), sc, lane, nodes, geoms);
 }
 
-// State of a group between its search and its shading (one loop iteration later).
-struct Pending {
-  f3 d, c;
-  PathTag tag;
-  bool valid;
-  int par, mark;
-  int level;  // 0: the group came from the launch's input queue (depth `depth`); 1: born in registers (depth + 1), see RegGroup
-  bool any;   // wave-uniform: a group is pending
-};
-// Two bounces per pass (k_bounce, `levels` == 2): the survivors of a group that came from memory do not go back to memory;
-// they stay where they are — lane i keeps its own new ray — and form the group the wave searches next, at depth + 1, with
-// the dead lanes idle.  Only the survivors of THAT group are compacted into the output queue (depth + 2).  The path state
-// of every second depth thus never touches HBM: -40 % of the rays read and -57 % of the survivors written per batch at
-// 1080p, bought with box tests and shading at ~70 % lane occupancy on every second group (the primitive-test chunks stay
-// dense: the candidate ring does not care which lanes own the rays).
-struct RegGroup {
-  f3 o, d, c;
-  PathTag tag;
-  bool valid;
-  bool any;  // wave-uniform: a register-born group is waiting to be searched
-};
-// Shading + retirement + compaction of a pending group from its resolved hit keys/records.
-// `depth` is the pending group's own depth, `ihash` the iteration-hash table of that depth.  keep (two bounces per pass,
-// a level-0 group): the survivors stay in registers as `rg` instead of being compacted into the output queue.  (KEEPS is
-// a template parameter and `rg` a reference: a pointer that may be null sends the whole group through scratch memory.)
-template <bool SMALL>
-PT_DEV void shade_pending(const SceneTables& sc, const Carry<SMALL>& cy, const Pending& pg, const ptd::Mat* __restrict__ mats, const uint32_t* ihash,
-                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, const BatchInfo& b,
-                          int depth, const Retire& rt,
-                          int32_t* __restrict__ counter, Deferred& df, int lane, bool keep, RegGroup& rg, int& kept) {
-  const unsigned long long best = cy.best[pg.par * 64 + lane];
-  const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
-  ShadeIO s;
-  s.o = mk(0.f, 0.f, 0.f);
-  s.d = pg.d;
-  s.c = pg.c;
-  s.alive = false;
-  Bounce bo;
-  bo.kind = 0;
-  f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
-  int k, pl;
-  sample_of(pg.tag, b, k, pl);
-  if (pg.valid) {
-    float ht = -1.0f;
-    int hmat = 0;
-    if (hit) {
-      ht = __uint_as_float((uint32_t)(best >> 32));
-      hmat = geoms[nodes[(uint32_t)best].geom].material;
-      const float* r = cy.rec + pg.par * 6 * 64 + lane;
-      hn = mk(r[0 * 64], r[1 * 64], r[2 * 64]);
-      hp = mk(r[3 * 64], r[4 * 64], r[5 * 64]);
-    }
-    bo = shade_decide(mats, b.trace_depth, depth, path_seed(pg.tag, k, pl, ihash, sc, b, depth), ht, hmat, s);
-  }
-  const bool alive = pg.valid && s.alive;
-  if (keep) {  // survivors stay in their lanes (RegGroup); only the retirement records are deferred
-    df.res.live = 0ull, df.res.base = 0;
-    df.res.rpos = retire_reserve(rt, pg.valid && !s.alive, k);
-  } else {
-    df.res = retire_and_reserve<true>(pg.valid, s, k, pl, rt, counter, lane);
-  }
-  if (alive && !(kAblate && (b.debug & 8))) shade_bounce(bo, hn, hp, s);
-  df.s = s;
-  df.tag = pg.tag;
-  df.alive = keep ? false : alive;
-  df.dead = pg.valid && !s.alive;
-  df.any = true;
-  if (keep) {
-    const unsigned long long live = __ballot(alive);
-    rg.o = s.o, rg.d = s.d, rg.c = s.c, rg.tag = pg.tag;
-    rg.valid = alive;
-    rg.any = live != 0ull;
-    kept += __popcll(live);
-  }
-}
-
 // ── depth 0 fused: generateRayFromCamera + computeIntersections + shadeAndExtendRays ────────
 // Primary rays are a pure function of the sample id, so depth 0 needs no path state in memory at
 // all: the ray is built in registers, traced with the same wave-cooperative search, shaded, and
@@ -1774,7 +1670,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
                                                     int32_t* __restrict__ cnt0, int32_t* __restrict__ cnt_out,
                                                     ptd::PathBuf out, ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // the retirement fill levels come first
+  char* lds = reinterpret_cast<char*>(lds_raw);
   static_assert(!(GRID && TABLES_IN_LDS), "the grid walk reads the tables from memory");
   const int nb_top = GRID ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
@@ -1835,7 +1731,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
+  const Retire rt = retire_of(ret, q);
   // the queue's samples, iteration-major: entry j = k * my_nq + jj is chunk q + jj * Q of iteration k (same map as k_generate)
   const QueueShare sh = queue_share(b, qs, q);
   if (r == 0 && lane == 0) cnt0[(size_t)q * qs.cnt_stride] = b.K * sh.my_pixels;
@@ -1870,8 +1766,8 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
     }
-    df.res = retire_and_reserve<true>(valid, s, k, pl, rt, counter, lane);
     const bool alive = valid && s.alive;
+    df.res = reserve_group(alive, valid && !s.alive, &rt.cnt[k], counter, b.flat != 0, lane);
     if (alive) shade_bounce(bo, hn, hp, s);
     df.s = s;
     df.tag = PathTag{slot, phash, k};
@@ -1901,7 +1797,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
     const int slot = make_slot(b, k, pl);
     const int p = global_pixel(b, pl);  // global pixel index
-    const uint32_t phash = utilhash((uint32_t)p);  // rides along with the path from here on (kTagged)
+    const uint32_t phash = utilhash((uint32_t)p);
     float jx = 0.f, jy = 0.f;
     if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
     const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
@@ -1942,127 +1838,6 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     }
   }
   flush_deferred(df, qbase, out, rt, b);
-  retire_end(rt, ret, b, q, r, lane);
-}
-
-// ── depth >= 1 fused: computeIntersections + shadeAndExtendRays + compaction ───────────────
-// Same pipeline as k_primary, but the ray comes from the previous depth's queues.  The hit record
-// never leaves the CU (LDS + registers), which removes its 32-B write and 32-B read per ray and the
-// re-read of the path state by a separate shading kernel: 40 B read + 40 B (survivor) or 12 B
-// (retired) written per ray, against 56 + 100 B for the two-kernel form.  The unfused k_shade is
-// HBM-bound (5.1 TB/s measured) while k_intersect is VALU-bound, so fusing lets the shading traffic
-// overlap the search instead of following it.
-// levels == 2: two bounces per pass (RegGroup) — the input queue holds depth `depth`, the output queue receives depth
-// `depth` + 2, and cnt_mid only the NUMBER of depth + 1 rays (statistics: they never existed in memory).
-// (TWO is a template parameter: the register-born group costs ~20 VGPRs, which the global-table variant does not have.)
-template <bool TABLES_IN_LDS, bool TWO = false>
-__global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc, BatchInfo b, int depth, int levels_arg, ptd::Queues qs,
-                                                   const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_mid, int32_t* __restrict__ cnt_out,
-                                                   ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
-  extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // the retirement fill levels come first
-  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
-  const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
-  stage16(lds, sc.top, nb_top);
-  stage16(lds + nb_top, sc.mats, nb_mats);
-  const float4* top = reinterpret_cast<const float4*>(lds);
-  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
-  const ptd::Node* nodes = sc.nodes;
-  const ptd::Geom* geoms = sc.geoms;
-  int tbl = nb_top + nb_mats;
-  if (TABLES_IN_LDS) {
-    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
-    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
-    stage16(lds + tbl, sc.nodes, nb_nodes);
-    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
-    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
-    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
-    tbl += nb_nodes + nb_geoms;
-  }
-  const int levels = TWO ? levels_arg : 1;
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * carry_bytes<TABLES_IN_LDS>());  // after the per-wave blocks
-  iter_hash_fill(ihash, sc, b, depth);
-  if (levels > 1) iter_hash_fill(ihash + iter_hash_entries(sc), sc, b, depth + 1);  // second table: the register-born groups' depth
-  __syncthreads();
-  const int wib = threadIdx.x >> 6;
-  Carry<TABLES_IN_LDS> cy = carry_init<TABLES_IN_LDS>(lds + tbl + wib * carry_bytes<TABLES_IN_LDS>());
-  cy.debug = b.debug;
-  const int ntop = sc.num_top;
-  const int wave = blockIdx.x * kWavesPerBlock + wib;
-  const int lane = lane_id();
-  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
-  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t qbase = (int64_t)q * qs.cap;
-  const int last = qs.cap - 64 + lane;  // branch-free loads, clamped into the queue's own region
-  auto load = [&](int i) { return path_load(in, qbase + min(i, last)); };
-  PathRec nx = load(r * 64 + lane);
-#define PT_TOUCH_PREFETCH()                                                                                         \
-  asm volatile("" ::"v"(nx.o.x), "v"(nx.o.y), "v"(nx.o.z), "v"(nx.d.x), "v"(nx.d.y), "v"(nx.d.z), "v"(nx.c.x), "v"(nx.c.y), \
-               "v"(nx.c.z), "v"(nx.tag.slot), "v"(nx.tag.phash), "v"(nx.tag.k))
-  PT_TOUCH_PREFETCH();  // same wait point as inside the loop, so that the loop header needs no vector-memory wait
-  Pending pg;
-  pg.any = false;
-  Deferred df;
-  df.any = false;
-  int it = 0;
-  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
-  RegGroup rg;
-  rg.any = false;
-  rg.valid = false;
-  int kept = 0;  // rays of depth + 1 this wave has traced (wave-uniform)
-  int j = r;     // the wave's next group of the input queue
-  while (true) {
-    // source of this iteration's group: a register-born group first (it was shaded into being one iteration ago), else
-    // the next group of the input queue, else nothing (the pipeline drains: a pending group is still to be shaded)
-    const bool from_reg = TWO && rg.any;
-    const bool from_mem = !from_reg && j * 64 < n_q;
-    if (!from_reg && !from_mem && !pg.any) break;
-    f3 co, cd, cc;
-    PathTag ctag;
-    bool valid = false;
-    if (from_reg) {
-      co = rg.o, cd = rg.d, cc = rg.c, ctag = rg.tag, valid = rg.valid;
-      rg.any = false;
-    } else {
-      co = nx.o, cd = nx.d, cc = nx.c, ctag = nx.tag;
-      if (from_mem) {
-        valid = j * 64 + lane < n_q;
-        j += wq;
-        nx = load(j * 64 + lane);  // next group's paths in flight while this group is searched
-      }
-    }
-    const int par = it & 1;
-    if (from_reg || from_mem) {
-      cy.best[par * 64 + lane] = kNoHit;
-      carry_search<!TABLES_IN_LDS, 2>(cy, top, ntop, nodes, geoms, co, cd, valid, lane, par, sc.cull_margin, sc.top_xor);
-    }
-    if (pg.any) carry_drain_to(cy, pg.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
-    // vmcnt is one in-order counter: waiting for the prefetched paths at the top of the next iteration would also wait
-    // for everything issued after them — this iteration's stores and the reservation atomic, i.e. a full memory round
-    // trip per group.  Touch the prefetched registers HERE instead, where everything outstanding (the prefetch and the
-    // previous group's reservation) is a whole candidate search old, so that this is the iteration's only vector-memory
-    // wait; the stores and the atomic below then have until the same point of the next iteration.
-    PT_TOUCH_PREFETCH();
-    flush_deferred(df, qbase, out, rt, b);  // survivors / retirement records of the group shaded one iteration ago
-    if (pg.any) {
-      const bool keep = TWO && levels > 1 && pg.level == 0;  // its survivors become the next group, in registers
-      shade_pending(sc, cy, pg, mats, ihash + pg.level * iter_hash_entries(sc), nodes, geoms, b, depth + pg.level, rt, counter, df, lane,
-                    keep, rg, kept);
-    }
-    pg.d = cd;
-    pg.c = cc;
-    pg.tag = ctag;
-    pg.valid = valid;
-    pg.par = par;
-    pg.mark = cy.appended;
-    pg.level = from_reg ? 1 : 0;
-    pg.any = from_reg || from_mem;
-    ++it;
-  }
-  flush_deferred(df, qbase, out, rt, b);
-  if (levels > 1 && kept > 0 && lane == 0) atomicAdd(&cnt_mid[(size_t)q * qs.cnt_stride], kept);
-  retire_end(rt, ret, b, q, r, lane);
 }
 
 // ── ALL depths >= 1 in one launch: persistent lanes (k_paths) ─────────────────────────────────────────────────────────────────
@@ -2094,7 +1869,6 @@ __global__ __launch_bounds__(kBlock, kBounceWaves) void k_bounce(SceneTables sc,
 #endif
 constexpr int kPathsWaves = PT_PATHS_WAVES, kPathsMinReady = PT_PATHS_MIN_READY;
 constexpr int kSlotBytes = 64 * 16 + 64 * 16 + 64 * 4 + 64 * 4;  // planes 0, 1 (16 B per lane), colour.z, sample id
-constexpr int kPathsExtra = kSlotBytes + 64;                      // + 16 counters: paths retired per depth (statistics)
 typedef float v4f __attribute__((ext_vector_type(4)));
 PT_DEV uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 // memory -> LDS without passing through VGPRs: path record i of a queue (b0 / b1 / b2 = the queue's first record in planes 0,
@@ -2130,9 +1904,6 @@ PT_DEV void fetch_record_to_lds(const void* b0, const void* b1, const void* b2, 
       : [base] "s"(lds_base), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [o16] "v"(off16), [o8] "v"(off8)
       : "memory", "scc");
 }
-// __ballot() of the HIP headers goes through an integer compare (v_cndmask 0 / 1 + v_cmp per call when the predicate already
-// sits in a scalar register pair); the builtin takes the predicate as it is.
-PT_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // mask * 2 + bit in ONE instruction: v_addc_co_u32 takes the predicate as its carry-in (instead of v_mov + v_cndmask + v_or
 // per box test).  The bits end up in reverse order of the pushes.
 PT_DEV uint32_t push_bit(uint32_t m, bool bit) {
@@ -2218,75 +1989,143 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
     if (c.count >= 64) paths_chunk(c, 64, lane, o, d, geoms);
   }
 }
-template <bool TABLES_IN_LDS>
-__global__ __launch_bounds__(kBlock, kPathsWaves) void k_paths(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
+// MODE 0: scene tables in LDS, every leaf a top entry (cornell.txt: the form described above).
+// MODE 1: tables in memory, top list + per-lane subtree scans with work stealing (carry_search<true>);
+// MODE 2: tables in memory, uniform grid walk (grid_search).  Modes 1 and 2 run every pending candidate before they shade
+//         (a search of theirs files several chunks' worth, and stolen work files candidates under other lanes' names, so a
+//         per-lane mark would need cross-lane bookkeeping): all live lanes are searched and shaded in every round.
+//         The grid walk's rings leave no LDS for refill slots (three workgroups per CU with them: measured 17-22 % slower than
+//         the per-depth kernel it replaces), and its rounds take tens of microseconds: the next record of a lane waits in
+//         REGISTERS there, loaded a round ahead by ordinary loads (five waves per SIMD at the price of ~40 B / lane of scratch:
+//         measured faster than four without; prefetching only origin and direction and loading the rest on demand: slower).
+#ifndef PT_PATHS_SCAN_WAVES
+#define PT_PATHS_SCAN_WAVES 5
+#endif
+#ifndef PT_PATHS_GRID_WAVES
+#define PT_PATHS_GRID_WAVES 5
+#endif
+// LDS of a wave's per-iteration tables (k_paths): fill[K] and pre[K + 1]
+__host__ __device__ inline int paths_fill_wave_bytes(const SceneTables& sc) { return ((2 * sc.max_batch_iters + 1) * 4 + 15) & ~15; }
+__host__ __device__ inline int paths_fill_bytes(const SceneTables& sc) { return kWavesPerBlock * paths_fill_wave_bytes(sc); }
+template <int MODE>
+constexpr bool paths_slots_in_lds() { return MODE != 2; }
+template <int MODE>
+constexpr int paths_extra_bytes() { return (paths_slots_in_lds<MODE>() ? kSlotBytes : 0) + 256; }  // refill slots + 64 counters: paths retired per depth
+template <int MODE>
+constexpr int paths_wave_bytes() {
+  return (MODE == 0 ? kLanesBytes : MODE == 1 ? carry_bytes<false, 1>() : grid_wave_bytes<false>()) + paths_extra_bytes<MODE>();
+}
+template <int MODE>
+__global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PATHS_SCAN_WAVES : PT_PATHS_GRID_WAVES) void k_paths(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
                                                                ptd::PathBuf in, ptd::RetireBuf ret) {
-  static_assert(TABLES_IN_LDS, "k_paths: LDS-table scenes (every leaf a top entry)");
   extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);
-  const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  char* lds = reinterpret_cast<char*>(lds_raw) + paths_fill_bytes(sc);  // the waves' per-iteration tables come first
+  const int nb_top = MODE == 2 ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk replaces top list and subtrees
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
   stage16(lds + nb_top, sc.mats, nb_mats);
   const float4* top = reinterpret_cast<const float4*>(lds);
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
   int tbl = nb_top + nb_mats;
-  const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
-  const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
-  stage16(lds + tbl, sc.nodes, nb_nodes);
-  stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
-  const ptd::Node* nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
-  const ptd::Geom* geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
-  tbl += nb_nodes + nb_geoms;
-  constexpr int wave_bytes = kLanesBytes + kPathsExtra;
+  const ptd::Node* nodes = sc.nodes;
+  const ptd::Geom* geoms = sc.geoms;
+  if (MODE == 0) {
+    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
+    stage16(lds + tbl, sc.nodes, nb_nodes);
+    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
+    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
+    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
+    tbl += nb_nodes + nb_geoms;
+  }
+  constexpr int wave_bytes = paths_wave_bytes<MODE>();
+  constexpr int core_bytes = wave_bytes - paths_extra_bytes<MODE>();
   const int he = iter_hash_entries(sc);
-  uint32_t* tword = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * wave_bytes);  // [kMaxTop]: leaf | geom << 8 per top entry
-  int* lmat = reinterpret_cast<int*>(tword + kMaxTop);                                      // [64]: material of the leaf at threaded node index i
-  uint32_t* ihash = tword + kMaxTop + 64;                                                   // rows of the depths 1 .. trace_depth - 1
+  uint32_t* tword = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * wave_bytes);  // MODE 0: [kMaxTop] leaf | geom << 8 per top entry
+  int* lmat = reinterpret_cast<int*>(tword + (MODE == 0 ? kMaxTop : 0));                    // MODE 0: [64] material of the leaf at threaded node index i
+  uint32_t* ihash = reinterpret_cast<uint32_t*>(lmat + (MODE == 0 ? 64 : 0));               // rows of the depths 1 .. trace_depth - 1
   for (int d = 1; d < b.trace_depth; ++d) iter_hash_fill(ihash + (d - 1) * he, sc, b, d);
-  for (int e = threadIdx.x; e < sc.num_top; e += blockDim.x) {
+  for (int e = threadIdx.x; MODE == 0 && e < sc.num_top; e += blockDim.x) {
     const int leaf = sc.top[e].idx, gi = sc.nodes[leaf].geom;
     tword[e] = (uint32_t)leaf | ((uint32_t)gi << 8);
     lmat[leaf & 63] = sc.geoms[gi].material;
   }
   __syncthreads();
   const int wib = threadIdx.x >> 6;
-  Lanes cy;
-  {
-    char* base = lds + tbl + wib * wave_bytes;
-    cy.best = reinterpret_cast<unsigned long long*>(base);
-    cy.rec = reinterpret_cast<float*>(base + 64 * 8);
-    cy.ent = reinterpret_cast<uint32_t*>(base + 64 * 8 + 6 * 64 * 4);
-    cy.head = cy.count = cy.appended = cy.processed = 0;
-  }
-  char* slots = lds + tbl + wib * wave_bytes + kLanesBytes;  // [64] x 16 B, [64] x 16 B, [64] x 4 B, [64] x 4 B
-  int* died = reinterpret_cast<int*>(slots + kSlotBytes);    // [16]: paths of this wave retired AT depth d (deeper than 15: in [15])
+  char* wbase = lds + tbl + wib * wave_bytes;
+  Lanes cy;  // MODE 0
+  cy.best = reinterpret_cast<unsigned long long*>(wbase);
+  cy.rec = reinterpret_cast<float*>(wbase + 64 * 8);
+  cy.ent = reinterpret_cast<uint32_t*>(wbase + 64 * 8 + 6 * 64 * 4);
+  cy.head = cy.count = cy.appended = cy.processed = 0;
+  Carry<false, 1> cb = carry_init<false, 1>(wbase);  // MODES 1, 2 (the same bytes)
+  CellRing cr{reinterpret_cast<uint32_t*>(wbase + carry_bytes<false, 1>()), 0, 0, nullptr};
+  if (MODE == 2) cb.gix = cr.ent + kCellRing, cr.rinv = reinterpret_cast<float*>(cr.ent + kCellRing + kRing);
+  cb.debug = b.debug;
+  constexpr bool SLOTS = paths_slots_in_lds<MODE>();
+  char* slots = wbase + core_bytes;  // SLOTS: [64] x 16 B, [64] x 16 B, [64] x 4 B, [64] x 4 B
+  int* died = reinterpret_cast<int*>(slots + (SLOTS ? kSlotBytes : 0));  // [64]: paths of this wave retired AT depth d (statistics; PT_MAX_DEPTH = 64)
   const int ntop = sc.num_top;
   const int wave = blockIdx.x * kWavesPerBlock + wib;
   const int lane = lane_id();
-  if (lane < 16) died[lane] = 0;
+  died[lane] = 0;
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
+  const Retire rt = retire_of(ret, q);
   const size_t per_depth = (size_t)qs.Q * qs.cnt_stride;
-  const int n_q = cnt[per_depth * 1 + (size_t)q * qs.cnt_stride];  // depth-1 rays of the queue (k_primary's survivors)
   const int64_t qbase = (int64_t)q * qs.cap;
-  // the wave's slice of the queue's input
-  const int per = (n_q + wq - 1) / wq;
-  const int lo = min(r * per, n_q), hi = min(lo + per, n_q);
+  // The queue's depth-1 rays: one list per iteration k (k_primary's survivors; n_k = the low word of cnt[q][k], final before
+  // this launch).  pre[k] = rays in the lists before list k; the wave's slice [lo, hi) of the concatenated lists; fill[k] = where
+  // the wave's next record of iteration k goes in region (q, k): behind depth 0's (pixels - n_k) and behind the records of the
+  // rays of list k that lie before the slice (they belong to the waves before this one, which retire exactly those).
+  int* fill = reinterpret_cast<int*>(reinterpret_cast<char*>(lds_raw) + wib * paths_fill_wave_bytes(sc));  // [K]
+  int* pre = fill + sc.max_batch_iters;                                                                    // [K + 1]
+  int total = 0;
+  for (int k0 = 0; k0 < b.K; k0 += 64) {
+    const int kk = k0 + lane;
+    const int n = kk < b.K ? (int)(uint32_t)rt.cnt[kk] : 0;
+    int sum;
+    const int before = wave_prefix6(n, sum);
+    if (kk < b.K) pre[kk] = total + before;
+    total += sum;
+  }
+  if (lane == 0) pre[b.K] = total;
+  const int per = (total + wq - 1) / wq;
+  const int lo = min(r * per, total), hi = min(lo + per, total);
+  const int my_pixels = queue_share(b, qs, q).my_pixels;
+  for (int kk = lane; kk < b.K; kk += 64) {
+    const int n = pre[kk + 1] - pre[kk];
+    fill[kk] = (my_pixels - n) + min(max(lo - pre[kk], 0), n);
+  }
+  if (r == 0 && lane == 0) cnt[per_depth * 1 + (size_t)q * qs.cnt_stride] = total;  // statistics: rays traced at depth 1
+  int kc = 0;  // wave-uniform: a list at or before the one rank `streamed` lies in
+  // path index (inside the queue's region) of the ray of global rank i
+  auto locate = [&](int i) {
+    int kk = kc;
+    while (i >= pre[kk + 1]) ++kk;  // (i < total = pre[K]; empty lists are stepped over)
+    return kk * rt.seg_cap + (i - pre[kk]);
+  };
   const uint32_t s_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(slots));
   const uint32_t s16 = s_base + (uint32_t)lane * 16u, s4 = s_base + 2048u + (uint32_t)lane * 4u;
   // issue the transfer of path record `i` of the queue into this lane's slot
   const ptd::Word4 *in0 = uniform_ptr(in.r + qbase), *in1 = uniform_ptr(in.r + in.stride + qbase);
   const float* in2 = uniform_ptr(reinterpret_cast<const float*>(in.r + 2 * in.stride) + 2 * qbase);
-  auto fetch = [&](int i) { fetch_record_to_lds(in0, in1, in2, i, s_base); };
+  PathRec nx;  // !SLOTS: the lane's next record, in registers
+  nx.o = nx.d = nx.c = mk(0.f, 0.f, 0.f), nx.tag = PathTag{0, 0u, 0};
+  auto fetch = [&](int i) {
+    const int at = locate(i);
+    if constexpr (SLOTS) fetch_record_to_lds(in0, in1, in2, at, s_base);
+    else nx = path_load(in, qbase + at);
+  };
   // lane state
   f3 o = mk(0.f, 0.f, 0.f), d = o, c = o;
   int slot = 0, depth = 1, mark = 0, rpos = 0;
   uint32_t phash = 0u;
   bool valid = false, fresh = false, owes = false;  // owes: the lane's path died and its retirement record is not stored yet
+  while (kc + 1 < b.K && lo >= pre[kc + 1]) ++kc;
   bool has_next = lo + lane < hi;
   if (has_next) fetch(lo + lane);
   int streamed = min(lo + 64, hi);  // records handed to slots so far: [lo, streamed)
+  while (kc + 1 < b.K && streamed >= pre[kc + 1]) ++kc;
   while (true) {
     // ── refill: dead lanes take the record waiting in their slot; the slot gets the next record of the slice ──
     const bool take = !valid && has_next;
@@ -2295,17 +2134,21 @@ __global__ __launch_bounds__(kBlock, kPathsWaves) void k_paths(SceneTables sc, B
       v4f w0, w1;
       float cz;
       int nslot;
-      // everything outstanding here (last refill's transfers, last refill's retirement stores) is a whole iteration old
-      asm volatile(
-          "s_waitcnt vmcnt(0)\n\t"
-          "ds_read_b128 %0, %4\n\t"
-          "ds_read_b128 %1, %4 offset:1024\n\t"
-          "ds_read_b32 %2, %5\n\t"
-          "ds_read_b32 %3, %5 offset:256\n\t"
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(w0), "=&v"(w1), "=&v"(cz), "=&v"(nslot)
-          : "v"(s16), "v"(s4)
-          : "memory");
+      if constexpr (SLOTS) {
+        // everything outstanding here (last refill's transfers, last refill's retirement stores) is a whole iteration old
+        asm volatile(
+            "s_waitcnt vmcnt(0)\n\t"
+            "ds_read_b128 %0, %4\n\t"
+            "ds_read_b128 %1, %4 offset:1024\n\t"
+            "ds_read_b32 %2, %5\n\t"
+            "ds_read_b32 %3, %5 offset:256\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(w0), "=&v"(w1), "=&v"(cz), "=&v"(nslot)
+            : "v"(s16), "v"(s4)
+            : "memory");
+      } else {
+        w0 = v4f{nx.o.x, nx.o.y, nx.o.z, nx.d.x}, w1 = v4f{nx.d.y, nx.d.z, nx.c.x, nx.c.y}, cz = nx.c.z, nslot = nx.tag.slot;
+      }
       if (owes) {  // the record of the path that died in this lane (its colour and sample id are still here)
         const int k = (int)((uint32_t)slot >> b.slot_shift), pl = slot & ((1 << b.slot_shift) - 1);
         retire_store(rt, true, k, rpos, pl, c);
@@ -2322,17 +2165,28 @@ __global__ __launch_bounds__(kBlock, kPathsWaves) void k_paths(SceneTables sc, B
         if (has_next) fetch(streamed + rank);
       }
       streamed = min(streamed + (int)__popcll(tm), hi);
+      while (kc + 1 < b.K && streamed >= pre[kc + 1]) ++kc;
     }
     if (!ballot(valid)) break;  // every path of the slice has retired
-    // ── search: box tests + appends for the lanes with a new ray; full chunks as the ring fills ──
-    if (ballot(fresh)) paths_search(cy, top, tword, ntop, geoms, o, d, fresh, lane, mark);
-    fresh = false;
-    // ── which lanes are resolved?  Too few, with candidates pending: run them as a partial chunk ──
-    bool ready = valid && (cy.processed - mark) >= 0;
-    if (cy.count > 0 && __popcll(ballot(ready)) < kPathsMinReady) {
-      paths_chunk(cy, cy.count, lane, o, d, geoms);  // count < 64 here
+    bool ready;
+    if constexpr (MODE == 0) {
+      // ── search: box tests + appends for the lanes with a new ray; full chunks as the ring fills ──
+      if (ballot(fresh)) paths_search(cy, top, tword, ntop, geoms, o, d, fresh, lane, mark);
+      // ── which lanes are resolved?  Too few, with candidates pending: run them as a partial chunk ──
+      ready = valid && (cy.processed - mark) >= 0;
+      if (cy.count > 0 && __popcll(ballot(ready)) < kPathsMinReady) {
+        paths_chunk(cy, cy.count, lane, o, d, geoms);  // count < 64 here
+        ready = valid;
+      }
+    } else {
+      // ── search of every live lane (all of them have a new ray), then all its candidates ──
+      cb.best[lane] = kNoHit;
+      if constexpr (MODE == 2) grid_search<1>(cb, cr, sc, nodes, geoms, o, d, valid, lane, 0);
+      else carry_search<true, 1>(cb, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
+      while (cb.count > 0) carry_chunk<false, 1, false, MODE == 2>(cb, min(64, cb.count), lane, nodes, geoms);
       ready = valid;
     }
+    fresh = false;
     // ── shade the resolved lanes ──
     {
       const unsigned long long best = cy.best[lane];
@@ -2351,17 +2205,23 @@ __global__ __launch_bounds__(kBlock, kPathsWaves) void k_paths(SceneTables sc, B
         int hmat = 0;
         if (hit) {
           ht = __uint_as_float((uint32_t)(best >> 32));
-          hmat = lmat[(uint32_t)best & 63u];
           const float* rr = cy.rec + lane;
           hn = mk(rr[0 * 64], rr[1 * 64], rr[2 * 64]);
           hp = mk(rr[3 * 64], rr[4 * 64], rr[5 * 64]);
+          if constexpr (MODE == 0) {
+            hmat = lmat[(uint32_t)best & 63u];
+          } else {
+            const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
+            hmat = G->material;
+            if (MODE == 2) hn = finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
+          }
         }
         const uint32_t ih = he > 0 ? ihash[(depth - 1) * he + k] : iter_hash(b.iter_first + k, depth);
         bo = shade_decide(mats, b.trace_depth, depth, ih ^ phash, ht, hmat, s);
       }
       const bool alive = ready && s.alive, dead = ready && !s.alive;
-      const int rp = retire_reserve(rt, dead, k);
-      if (dead) atomicAdd(&died[min(depth, 15)], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
+      const int rp = dead ? atomicAdd(&fill[k], 1) : 0;  // lanes of one iteration get consecutive records
+      if (dead) atomicAdd(&died[depth & 63], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
       if (alive) shade_bounce(bo, hn, hp, s);
       if (ready) {
         c = s.c;
@@ -2373,116 +2233,11 @@ __global__ __launch_bounds__(kBlock, kPathsWaves) void k_paths(SceneTables sc, B
   // statistics: rays traced at depth d >= 2 = this wave's paths retired at depth >= d (row 1 holds the queue's input count already)
   if (lane == 0) {
     int reached = 0;
-    for (int dd = min(b.trace_depth - 1, 15); dd >= 2; --dd) {
+    for (int dd = min(b.trace_depth - 1, 63); dd >= 2; --dd) {
       reached += died[dd];
       if (reached) atomicAdd(&cnt[per_depth * dd + (size_t)q * qs.cnt_stride], reached);
     }
   }
-  retire_end(rt, ret, b, q, r, lane);
-}
-
-// ── depth >= 1 for scenes with subtrees below the top list (thousands of primitives) ────────────────
-// Same stages as k_bounce<false>, one group at a time per wave: load, search (ring + chunks as before), drain, shade, emit,
-// with what is needed only at the end (throughput colour, slot) re-read from memory.  k_bounce's pipelining (next group
-// prefetched, previous group pending, survivors deferred, double-buffered LDS) costs ~40 VGPRs and 3.5 KB of LDS per wave and
-// buys nothing when a group takes ~20 us; without it the kernel needs 75 VGPRs and 4.3 KB per wave, which leaves the LDS for
-// the hot part of the scan tree (see scan_fetch).  Compiled for 5 waves per SIMD (no spills; at 6 the exact grid kernel spills two registers): the BVH scan runs the same at
-// 4, 5 and 6, the grid walk 3 % faster at 5 or 6 than at 4, both 7-15 % slower at 8 (64 VGPRs, spills).
-#ifndef PT_BIG_WAVES
-#define PT_BIG_WAVES 5
-#endif
-constexpr int kBigWaves = PT_BIG_WAVES;
-#ifndef PT_LITE_WAVES
-#define PT_LITE_WAVES 6
-#endif
-// SMALL (A/B experiment, debug_flags 128 on a scene whose tables fit LDS): the same one-group-at-a-time kernel with the scene
-// tables staged in LDS like k_bounce<true> — is the cornell bounce kernel better off with more waves and no pipelining?
-template <bool GRID, bool SMALL = false>
-__global__ __launch_bounds__(kBlock, SMALL ? PT_LITE_WAVES : kBigWaves) void k_bounce_big(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
-                                                                const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
-                                                                ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
-  extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw) + retire_lds_bytes(sc);  // the retirement fill levels come first
-  const int nb_top = GRID ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk replaces top list and subtrees
-  const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
-  stage16(lds, sc.top, nb_top);
-  stage16(lds + nb_top, sc.mats, nb_mats);
-  const float4* top = reinterpret_cast<const float4*>(lds);
-  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
-  const ptd::Node* nodes = sc.nodes;
-  const ptd::Geom* geoms = sc.geoms;
-  int tbl = nb_top + nb_mats;
-  if (SMALL) {
-    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
-    const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
-    stage16(lds + tbl, sc.nodes, nb_nodes);
-    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
-    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
-    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
-    tbl += (nb_nodes + nb_geoms + 15) & ~15;
-  }
-  constexpr int kWaveBytes = GRID ? grid_wave_bytes<false>() : carry_bytes<SMALL, 1>();
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * kWaveBytes);
-  iter_hash_fill(ihash, sc, b, depth);
-  __syncthreads();
-  const int wib = threadIdx.x >> 6;
-  Carry<SMALL, 1> cy = carry_init<SMALL, 1>(lds + tbl + wib * kWaveBytes);
-  CellRing cr{reinterpret_cast<uint32_t*>(lds + tbl + wib * kWaveBytes + carry_bytes<SMALL, 1>()), 0, 0, nullptr};
-  if (GRID) cy.gix = cr.ent + kCellRing, cr.rinv = reinterpret_cast<float*>(cr.ent + kCellRing + kRing);
-  cy.debug = b.debug;
-  const int ntop = sc.num_top;
-  const int wave = blockIdx.x * kWavesPerBlock + wib;
-  const int lane = lane_id();
-  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const Retire rt = retire_begin(lds_raw, ret, sc, b, q, r, wib, lane);
-  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t qbase = (int64_t)q * qs.cap;
-  const int last = qs.cap - 64 + lane;
-  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
-  for (int j = r; j * 64 < n_q; j += wq) {
-    const int i = j * 64 + lane;
-    const bool valid = i < n_q;
-    const int64_t at = qbase + min(i, last);
-    {
-      f3 o, d;
-      path_load_ray(in, at, o, d);
-      cy.best[lane] = kNoHit;
-      if constexpr (GRID) grid_search<1>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
-      else carry_search<!SMALL, 1>(cy, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
-    }
-    while (cy.count > 0) carry_chunk<SMALL, 1, false, GRID>(cy, min(64, cy.count), lane, nodes, geoms);
-    // shade: direction, colour and tag re-read from memory (planes 1 and 2; the search needed the registers)
-    ShadeIO s;
-    s.o = mk(0.f, 0.f, 0.f);
-    PathTag tag;
-    path_load_tail(in, at, s.d, s.c, tag);
-    s.alive = false;
-    int k, pl;
-    sample_of(tag, b, k, pl);
-    const unsigned long long best = cy.best[lane];
-    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
-    Bounce bo;
-    bo.kind = 0;
-    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
-    if (valid) {
-      float ht = -1.0f;
-      int hmat = 0;
-      if (hit) {
-        ht = __uint_as_float((uint32_t)(best >> 32));
-        const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
-        hmat = G->material;
-        hn = mk(cy.rec[0 * 64 + lane], cy.rec[1 * 64 + lane], cy.rec[2 * 64 + lane]);
-        hp = mk(cy.rec[3 * 64 + lane], cy.rec[4 * 64 + lane], cy.rec[5 * 64 + lane]);
-        if (GRID) hn = finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
-      }
-      bo = shade_decide(mats, b.trace_depth, depth, path_seed(tag, k, pl, ihash, sc, b, depth), ht, hmat, s);
-    }
-    const Reservation res = retire_and_reserve(valid, s, k, pl, rt, counter, lane);
-    const bool alive = valid && s.alive;
-    if (alive) shade_bounce(bo, hn, hp, s);
-    emit_survivors(res, alive, s, tag, qbase, out);
-  }
-  retire_end(rt, ret, b, q, r, lane);
 }
 
 // test-only stage: explicit (iter, pixel) per path, in-place, no compaction
@@ -2513,35 +2268,31 @@ __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trac
 
 // ───────────────────────────── gather / stats / preview ────────────────────
 // finalGather (pathtrace.cu:439-444) from the retirement records: one workgroup per queue.  The queue owns the same
-// pixels in every iteration (ptd::Queues), at most kCollectPixels of them per pass; for k = 0, 1, ... the records of
-// (q, k) — R private segments, read with coalesced 16-byte loads — are dropped into an LDS tile indexed by pixel, and
-// every thread adds the tile to the accumulators of its pixels: image[p] = (((image[p] + c_0) + c_1) + ...), the
-// order in which successive finalGather launches would have added them.  Nothing is scattered through memory: the
-// segments are read once front to back, the image is read and written once.  Queues with more pixels than a tile
-// (frames beyond 4K at Q = 256 .. 1024) take several passes over their records.
-constexpr int kCollectThreads = 1024, kCollectWaves = kCollectThreads / 64;
-constexpr int kCollectPPT = 8;                                // pixels per thread and pass
+// pixels in every iteration (ptd::Queues), at most kCollectPixels of them per pass; for k = 0, 1, ... region (q, k) — one
+// record per pixel of the queue, contiguous, exactly full (pt_device.h RetireBuf) — is read front to back with coalesced
+// 16-byte loads and dropped into an LDS tile indexed by pixel, and every thread adds the tile to the accumulators of its
+// pixels: image[p] = (((image[p] + c_0) + c_1) + ...), the order in which successive finalGather launches would have added
+// them.  Nothing is scattered through memory: the regions are read once, the image is read and written once.  Queues
+// with more pixels than a tile (frames beyond 4K at Q = 256 .. 1024) take several passes over their records.
+constexpr int kCollectThreads = 1024;
+constexpr int kCollectPPT = 8;                                // pixels (and records) per thread and pass
 constexpr int kCollectPixels = kCollectPPT * kCollectThreads;  // 8192 pixels = 128 chunks: 96 KB of LDS
-// the queue's fill levels are staged in LDS while they are few (R * kmax <= 8192: 32 KB), otherwise read from memory
-__host__ __device__ inline bool collect_stages_fill(const ptd::RetireBuf& ret) { return ret.R * ret.kmax <= 8192; }
-__host__ __device__ inline int collect_lds_bytes(const ptd::RetireBuf& ret) {
-  return kCollectPixels * 12 + (collect_stages_fill(ret) ? ((ret.R * ret.kmax * 4 + 15) & ~15) : 0);
-}
-// the first (up to) 512 records of a segment, eight per lane
+__host__ __device__ inline int collect_lds_bytes() { return kCollectPixels * 12; }
+// records i0 + t, i0 + t + 1024, ... of a region, eight per thread
 struct CollectChunk {
-  ptd::Word4 v[8];
+  ptd::Word4 v[kCollectPPT];
 };
-PT_DEV void collect_load(const ptd::Word4* rec, int n, int i0, int lane, CollectChunk& c) {
+PT_DEV void collect_load(const ptd::Word4* rec, int n, int i0, CollectChunk& c) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = i0 + u * 64 + lane;
+  for (int u = 0; u < kCollectPPT; ++u) {
+    const int i = i0 + u * kCollectThreads + (int)threadIdx.x;
     c.v[u] = rec[i < n ? i : (n > 0 ? n - 1 : 0)];
   }
 }
-PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int lane, int Q, float inv_q, int first, float* tile) {
+PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int Q, float inv_q, int first, float* tile) {
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = i0 + u * 64 + lane;
+  for (int u = 0; u < kCollectPPT; ++u) {
+    const int i = i0 + u * kCollectThreads + (int)threadIdx.x;
     const int pl = __float_as_int(c.v[u].w);
     int jj, qq;
     divmod(pl >> 6, Q, inv_q, jj, qq);
@@ -2551,23 +2302,12 @@ PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int lane, int 
 }
 __global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Queues qs, ptd::RetireBuf ret, float* __restrict__ image) {
   extern __shared__ float4 lds_raw[];
-  float* tile = reinterpret_cast<float*>(lds_raw);                  // [kCollectPixels][3]
-  int* fill = reinterpret_cast<int*>(tile + 3 * kCollectPixels);    // [R][kmax] fill levels of the queue's segments
+  float* tile = reinterpret_cast<float*>(lds_raw);  // [kCollectPixels][3]
   const int q = blockIdx.x;
-  const int wib = threadIdx.x >> 6, lane = lane_id();
   const QueueShare sh = queue_share(b, qs, q);
   const float inv_q = 1.0f / (float)qs.Q;
-  const int64_t s_q = (int64_t)q * ret.R * ret.kmax;
-  const bool staged = collect_stages_fill(ret);
-  if (staged)
-    for (int i = threadIdx.x; i < ret.R * ret.kmax; i += kCollectThreads) fill[i] = ret.cnt[s_q + i];
-  __syncthreads();
-  auto fill_of = [&](int r, int k) { return r < ret.R ? (staged ? fill[r * ret.kmax + k] : ret.cnt[s_q + r * ret.kmax + k]) : 0; };
-  // wave w reads the segments r = w and w + 16 of (q, k) (further ones, R > 32, without the prefetch)
-  const int r0 = wib, r1 = wib + kCollectWaves;
-  // (a wave without a segment, r >= R, is pointed at segment 0 and reads nothing of it: its fill level counts as 0)
-  const ptd::Word4* rec0 = ret.rec + (s_q + (int64_t)(r0 < ret.R ? r0 : 0) * ret.kmax) * ret.seg_cap;
-  const ptd::Word4* rec1 = ret.rec + (s_q + (int64_t)(r1 < ret.R ? r1 : 0) * ret.kmax) * ret.seg_cap;
+  const ptd::Word4* rec = ret.rec + (int64_t)q * ret.kmax * ret.seg_cap;  // region (q, 0)
+  const int n = sh.my_pixels;                                              // records per region
   for (int first = 0; first < sh.my_nq * 64; first += kCollectPixels) {  // one pass per kCollectPixels of the queue's pixels
     float acc[kCollectPPT][3];
     // thread t owns the queue pixels first + t + kCollectThreads * m: chunk jj = index >> 6 is tile chunk q + jj * Q
@@ -2578,36 +2318,17 @@ __global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Q
       const bool mine = li < sh.my_nq * 64 && pl < b.N;
       acc[m][0] = mine ? image[3 * (int64_t)pl] : 0.f, acc[m][1] = mine ? image[3 * (int64_t)pl + 1] : 0.f, acc[m][2] = mine ? image[3 * (int64_t)pl + 2] : 0.f;
     }
-    // software pipeline: the first 512 records of the wave's two segments of iteration k + 1 are in flight while
-    // iteration k is summed (the tile is reused every iteration, so the two barriers per iteration stay)
-    CollectChunk c0, c1;
-    int n0 = fill_of(r0, 0), n1 = fill_of(r1, 0);
-    collect_load(rec0, n0, 0, lane, c0);
-    collect_load(rec1, n1, 0, lane, c1);
+    // software pipeline: the first 8192 records of iteration k + 1 are in flight while iteration k is summed (the tile is
+    // reused every iteration, so the two barriers per iteration stay)
+    CollectChunk c;
+    collect_load(rec, n, 0, c);
     for (int k = 0; k < b.K; ++k) {
-      collect_scatter(c0, n0, 0, lane, qs.Q, inv_q, first, tile);
-      collect_scatter(c1, n1, 0, lane, qs.Q, inv_q, first, tile);
-      for (int i0 = 512; i0 < n0; i0 += 512) {  // segments longer than one chunk
-        collect_load(rec0 + (int64_t)k * ret.seg_cap, n0, i0, lane, c0);
-        collect_scatter(c0, n0, i0, lane, qs.Q, inv_q, first, tile);
+      collect_scatter(c, n, 0, qs.Q, inv_q, first, tile);
+      for (int i0 = kCollectPixels; i0 < n; i0 += kCollectPixels) {  // regions longer than one chunk (several passes only)
+        collect_load(rec + (int64_t)k * ret.seg_cap, n, i0, c);
+        collect_scatter(c, n, i0, qs.Q, inv_q, first, tile);
       }
-      for (int i0 = 512; i0 < n1; i0 += 512) {
-        collect_load(rec1 + (int64_t)k * ret.seg_cap, n1, i0, lane, c1);
-        collect_scatter(c1, n1, i0, lane, qs.Q, inv_q, first, tile);
-      }
-      for (int r = wib + 2 * kCollectWaves; r < ret.R; r += kCollectWaves) {  // R > 32 only
-        const int n = fill_of(r, k);
-        const ptd::Word4* rec = ret.rec + (s_q + (int64_t)r * ret.kmax + k) * ret.seg_cap;
-        for (int i0 = 0; i0 < n; i0 += 512) {
-          collect_load(rec, n, i0, lane, c0);
-          collect_scatter(c0, n, i0, lane, qs.Q, inv_q, first, tile);
-        }
-      }
-      if (k + 1 < b.K) {
-        n0 = fill_of(r0, k + 1), n1 = fill_of(r1, k + 1);
-        collect_load(rec0 + (int64_t)(k + 1) * ret.seg_cap, n0, 0, lane, c0);
-        collect_load(rec1 + (int64_t)(k + 1) * ret.seg_cap, n1, 0, lane, c1);
-      }
+      if (k + 1 < b.K) collect_load(rec + (int64_t)(k + 1) * ret.seg_cap, n, 0, c);
       __syncthreads();
 #pragma unroll
       for (int m = 0; m < kCollectPPT; ++m) {
@@ -2623,8 +2344,8 @@ __global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Q
       if (li < sh.my_nq * 64 && pl < b.N) image[3 * (int64_t)pl] = acc[m][0], image[3 * (int64_t)pl + 1] = acc[m][1], image[3 * (int64_t)pl + 2] = acc[m][2];
     }
   }
-  // the records are consumed: empty segments for the next batch
-  for (int i = threadIdx.x; i < ret.R * ret.kmax; i += kCollectThreads) ret.cnt[s_q + i] = 0;
+  // the records are consumed: zero counters for the next batch
+  for (int i = threadIdx.x; i < ret.kmax; i += kCollectThreads) ret.cnt[(int64_t)q * ret.kmax + i] = 0ull;
 }
 
 __global__ void k_count_stats(ptd::Queues qs, int32_t* __restrict__ cnt, int depth_count,
@@ -2690,47 +2411,41 @@ inline int round16(int x) { return (x + 15) & ~15; }
 
 // ───────────────────────────── launch wrappers ─────────────────────────────
 int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false) {
-  int bytes = retire_lds_bytes(sc) + sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds +
-              iter_hash_entries(sc) * 4;
+  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds + iter_hash_entries(sc) * 4;
   if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
   if (primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + (in_lds ? round16(sc.num_geoms * 12) : 0);  // camera-relative copies
   return bytes;
 }
 int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
-int paths_lds_bytes(const SceneTables& sc) {  // one iteration-hash row is in fused_lds_bytes already
-  return fused_lds_bytes(sc, true, kLanesBytes + kPathsExtra) + kMaxTop * 4 + 64 * 4 + iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 2);
-}
-int big_lds_bytes(const SceneTables& sc) {
-  if (sc.use_grid)
-    return retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<false>() + iter_hash_entries(sc) * 4;
-  return retire_lds_bytes(sc) + sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * carry_bytes<false, 1>() +
-         iter_hash_entries(sc) * 4;
-}
-bool use_big(const SceneTables& sc) { return sc.big_kernel != 0 && !tables_in_lds(sc); }
-bool use_lite(const SceneTables& sc) { return sc.big_kernel != 0 && tables_in_lds(sc); }  // only ever on request (debug_flags 128)
-int lite_lds_bytes(const SceneTables& sc) {
-  return retire_lds_bytes(sc) + sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + round16(table_bytes(sc)) +
-         kWavesPerBlock * carry_bytes<true, 1>() + iter_hash_entries(sc) * 4;
+// k_paths' search form: 2 = uniform grid walk, 0 = scene tables in LDS (every leaf a top entry), 1 = top list + subtree scans
+int paths_mode(const SceneTables& sc) { return sc.use_grid ? 2 : (tables_in_lds(sc) ? 0 : 1); }
+int paths_lds_bytes(const SceneTables& sc, int mode) {
+  const int rows = iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 1), common = paths_fill_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + rows;
+  const int top = sc.num_top * (int)sizeof(ptd::TopEntry);
+  switch (mode) {
+    case 0: return common + top + round16(table_bytes(sc)) + kWavesPerBlock * paths_wave_bytes<0>() + kMaxTop * 4 + 64 * 4;
+    case 1: return common + top + kWavesPerBlock * paths_wave_bytes<1>();
+    default: return common + kWavesPerBlock * paths_wave_bytes<2>();
+  }
 }
 int primary_grid_lds_bytes(const SceneTables& sc) {
-  return retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<kD0>() + iter_hash_entries(sc) * 4;
+  return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<kD0>() + iter_hash_entries(sc) * 4;
 }
 // The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
 bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
-// Stage the scene tables in LDS only if every leaf is a top-list entry and staging does not cost the dominant kernel a
-// resident block per CU: measured on
-// random scenes at 1080p, 156 geoms (52 KB of tables, 1 block/CU) ran at 2.2 Gsamples/s from LDS and 4.5 from
-// global memory / L2 (4 blocks/CU); 26 geoms (8 KB) are equal either way; cornell's 2.3 KB keep all 4 blocks.
+// Stage the scene tables in LDS only if every leaf is a top-list entry and staging does not cost the dominant kernel
+// (k_paths) a resident block per CU against its form with the tables in memory.
 int lds_table_limit(const SceneTables& sc, int forced_bytes) {
   if (forced_bytes >= 0) return leaves_fit_top(sc) ? forced_bytes : -1;
   const int tbl = table_bytes(sc);
   int with = 0, without = 0;
-  if (tbl <= kLdsTableBytes && leaves_fit_top(sc) &&
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_bounce<true, false>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>())) != hipSuccess)
-    with = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_bounce<false, false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>())) != hipSuccess)
-    without = 1;
+  if (tbl <= kLdsTableBytes && leaves_fit_top(sc)) {
+    SceneTables in = sc;
+    in.lds_table_bytes = tbl;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_paths<0>, kBlock, paths_lds_bytes(in, 0)) != hipSuccess) with = 0;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_paths<1>, kBlock, paths_lds_bytes(sc, 1)) != hipSuccess) without = 1;
   (void)hipGetLastError();
   return (with >= without && with > 0) ? tbl : -1;
 }
@@ -2755,23 +2470,17 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false, false>, kBlock, 0);
       break;
     case kPrimary:
-      if (use_big(sc) && sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false, true>, kBlock, primary_grid_lds_bytes(sc));
+      if (sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false, true>, kBlock, primary_grid_lds_bytes(sc));
       else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true));
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
       break;
-    case kBounce:
-      if (use_big(sc) && sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big<true>, kBlock, big_lds_bytes(sc));
-      else if (use_big(sc)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce_big<false>, kBlock, big_lds_bytes(sc));
-      else if (use_lite(sc)) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (k_bounce_big<false, true>), kBlock, lite_lds_bytes(sc));
-      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<true, false>, kBlock, fused_lds_bytes(sc, true, carry_bytes<true>()));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, false>, kBlock, fused_lds_bytes(sc, false, carry_bytes<false>()));
-      break;
     case kPaths:
-      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<true>, kBlock, paths_lds_bytes(sc));
-      else n = 0;
+      if (paths_mode(sc) == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<0>, kBlock, paths_lds_bytes(sc, 0));
+      else if (paths_mode(sc) == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<1>, kBlock, paths_lds_bytes(sc, 1));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<2>, kBlock, paths_lds_bytes(sc, 2));
       break;
     case kShade:
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
       break;
   }
   if (e != hipSuccess || n < 1) n = 1;
@@ -2804,37 +2513,21 @@ void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd:
 
 void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
                     const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf ret) {
-  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
+  if (sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
   else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
 }
 
-// levels: bounces per pass the caller asks for (1 or 2); returns how many the launched kernel performs — 2 only from
-// k_bounce (the large-scene kernels trace one depth per pass) — so that the host advances its depth loop by that much.
-// cnt_mid: fill-level row of depth + 1 (two bounces per pass: receives the ray count only), cnt_out: row of depth + levels.
 void launch_paths(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret) {
-  hipLaunchKernelGGL(k_paths<true>, dim3(grid), dim3(kBlock), paths_lds_bytes(sc), s, sc, b, qs, cnt, in, ret);
+  const int bytes = paths_lds_bytes(sc, paths_mode(sc));
+  if (paths_mode(sc) == 0) hipLaunchKernelGGL(k_paths<0>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
+  else if (paths_mode(sc) == 1) hipLaunchKernelGGL(k_paths<1>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
+  else hipLaunchKernelGGL(k_paths<2>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
 }
-int launch_bounce(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, int levels, const ptd::Queues& qs,
-                  const int32_t* cnt_in, int32_t* cnt_mid, int32_t* cnt_out, ptd::PathBuf in, ptd::PathBuf out, ptd::RetireBuf ret) {
-  if (use_big(sc) && sc.use_grid) hipLaunchKernelGGL(k_bounce_big<true>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
-  else if (use_big(sc)) hipLaunchKernelGGL(k_bounce_big<false>, dim3(grid), dim3(kBlock), big_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
-  else if (use_lite(sc)) hipLaunchKernelGGL((k_bounce_big<false, true>), dim3(grid), dim3(kBlock), lite_lds_bytes(sc), s, sc, b, depth, qs, cnt_in, cnt_mid, in, out, ret);
-  else if (tables_in_lds(sc) && levels > 1) {  // the LDS-table kernel, two bounces per pass (on request: measured slower)
-    hipLaunchKernelGGL((k_bounce<true, true>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()) + iter_hash_entries(sc) * 4, s, sc, b, depth, 2, qs, cnt_in, cnt_mid, cnt_out, in, out, ret);
-    return 2;
-  } else if (tables_in_lds(sc)) {
-    hipLaunchKernelGGL((k_bounce<true, false>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, carry_bytes<true>()), s, sc, b, depth, 1, qs, cnt_in, cnt_mid, cnt_mid, in, out, ret);
-  } else {
-    hipLaunchKernelGGL((k_bounce<false, false>), dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, carry_bytes<false>()), s, sc, b, depth, 1, qs, cnt_in, cnt_mid, cnt_mid, in, out, ret);
-  }
-  return 1;
-}
-
 void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
                   const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
                   ptd::RetireBuf ret) {
-  const int bytes = retire_lds_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4;
+  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4;
   hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
                      ret);
 }
@@ -2845,8 +2538,8 @@ int flat_grid(int n, int cap) {
 }
 void launch_collect(hipStream_t s, const BatchInfo& b, const ptd::Queues& qs, ptd::RetireBuf ret, float* image_rgb) {
   // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking (per device: set on every launch, it is cheap)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, collect_lds_bytes(ret));
-  hipLaunchKernelGGL(k_collect, dim3(qs.Q), dim3(kCollectThreads), collect_lds_bytes(ret), s, b, qs, ret, image_rgb);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, collect_lds_bytes());
+  hipLaunchKernelGGL(k_collect, dim3(qs.Q), dim3(kCollectThreads), collect_lds_bytes(), s, b, qs, ret, image_rgb);
 }
 
 // Device self-check of the guarded IEEE sequences (namespace ieee) against the compiler's own expansions — pt_selfcheck_ieee.
@@ -2930,7 +2623,7 @@ const KernelApi kApi = {
 #else
     "fast",
 #endif
-    launch_generate, launch_primary, launch_bounce, launch_intersect, launch_shade, launch_collect, launch_count_stats,
+    launch_generate, launch_primary, launch_intersect, launch_shade, launch_collect, launch_count_stats,
     launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check, launch_paths};
 
 }  // namespace

@@ -97,21 +97,15 @@ typedef struct PtOptions {
                            /*    HIP events on the render stream (pt_get_stats)  */
   int32_t legacy_traversal; /* 1: per-lane BVH walk kernel instead of the wave-cooperative one (A/B) */
   int32_t debug_flags;      /* A-B switches with UNCHANGED results: 16 no closer-hit cull in the subtree scans, 32 no
-                               near-first subtree order, 64 / 128 force the pipelined / the high-occupancy depth >= 1
-                               kernel for scenes whose tables are not in LDS (default: by BVH size; 128 on a scene whose tables
-                               ARE in LDS runs the one-group-at-a-time kernel with LDS tables — an occupancy experiment: same time), 256 / 512 force /
-                               forbid the uniform-grid walk of the fused kernels (default: for large scenes, whichever of
-                               the BVH scan and up to three grid resolutions renders a few iterations fastest at pt_init), 1024 two bounces per pass in the fused
-                               bounce kernel of small scenes (the survivors of every other depth stay in registers instead of
-                               going through HBM; measured slower, kept as an experiment), 4096 all depths >= 1 of a batch in ONE launch (k_bounce_all: persistent lanes with their own depth, a dead
-                               lane takes the next depth-1 ray of its queue, no path state through HBM after depth 0; small-scene
-                               kernels, trace depth <= 16; an experiment: same image and statistics, same speed), 2048 keep the reference's
-                               leaf boxes for spheres (default for large scenes: tightened to the ellipsoid's box, PtStats.tight_leaves;
-                               pt_stage_intersect on such a scene then expects ray origins inside the scene bounds or at the camera).  Bits 0-3 are profiling ablations with WRONG results
-                               (1 no top list, 4 skip the primitive tests, 8 skip the bounce-direction sampling);
-                               they exist only in -DPT_ABLATE builds of the library (tools/pmc_ablate.sh) and
-                               pt_init fails on them otherwise (pt_library_has_ablations()).  (Environment,
-                               tests only: PT_LDS_TABLE_KB forces the LDS staging limit of the scene tables.) */
+                               near-first subtree order, 256 / 512 force / forbid the uniform-grid walk of the fused kernels
+                               (default: for large scenes, whichever of the BVH scan and up to three grid resolutions renders a
+                               few iterations fastest at pt_init), 2048 keep the reference's leaf boxes for spheres (default for
+                               large scenes: tightened to the ellipsoid's box, PtStats.tight_leaves; pt_stage_intersect on such
+                               a scene then expects ray origins inside the scene bounds or at the camera).  Bits 0-3 are
+                               profiling ablations with WRONG results (1 no top list, 4 skip the primitive tests, 8 skip the
+                               bounce-direction sampling); they exist only in -DPT_ABLATE builds of the library
+                               (tools/pmc_ablate.sh) and pt_init fails on them otherwise (pt_library_has_ablations()).
+                               (Environment, tests only: PT_LDS_TABLE_KB forces the LDS staging limit of the scene tables.) */
   int32_t unfused_primary;  /* 1: run depth 0 as generate + intersect + shade launches instead of the fused
                                primary kernel (A/B and stage-parity runs) */
   int32_t unfused_bounces;  /* 1: depths >= 1 as separate computeIntersections + shade launches (hit records

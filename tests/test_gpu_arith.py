@@ -125,9 +125,7 @@ def test_mode_is_deterministic_and_layout_neutral(scene_dir, arith):
     kernel forms do not change a bit."""
     res, spp = (200, 120), 7
     a = gpu(scene_dir["cornell"], res, spp, arith)
-    for kw in (dict(iters_per_batch=3), dict(num_queues=64, blocks_per_cu=2), dict(unfused_bounces=True), dict(unfused_primary=True),
-               dict(debug_flags=1024),   # 1024: two bounces per pass (survivors of every other depth stay in registers)
-               dict(debug_flags=4096)):  # 4096: one launch per depth (k_bounce) instead of all depths >= 1 in one launch (k_paths)
+    for kw in (dict(iters_per_batch=3), dict(num_queues=64, blocks_per_cu=2), dict(unfused_bounces=True), dict(unfused_primary=True)):
         b = gpu(scene_dir["cornell"], res, spp, arith, **kw)
         same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
         if kw.get("unfused_primary"):

@@ -60,10 +60,7 @@ def gpu_render(scene_path, res, spp, depth=None, first=1, **kw):
     ("stress_big", (160, 90), 4, 8, dict(debug_flags=16)),
     ("stress_big", (160, 90), 4, 8, dict(debug_flags=32)),
     ("stress_big", (160, 90), 4, 8, dict(debug_flags=48, unfused_bounces=True)),
-    # depth >= 1 kernel choice for global-table scenes is result-neutral: force the pipelined (64) / the high-occupancy (128) one
-    ("stress_big", (160, 90), 4, 8, dict(debug_flags=64)),
-    ("stress_big", (160, 90), 4, 8, dict(debug_flags=128)),
-    ("stress", (160, 90), 6, 8, dict(debug_flags=128, iters_per_batch=2)),
+    ("cornell", (97, 61), 5, 20, dict(iters_per_batch=2)),            # a depth beyond the reference scenes': 19 bounce depths in k_paths
     # the uniform grid over the leaf boxes (large evenly spread scenes) is result-neutral: force it (256) on scenes of every
     # size — cornell's 7 leaves give a one-cell grid — and forbid it (512) where the library would choose it
     ("cornell", (200, 120), 7, 8, dict(debug_flags=256)),
@@ -173,22 +170,19 @@ def test_striped_tiles_compose(scene_dir):
     ((320, 200), dict(num_queues=16, blocks_per_cu=1, iters_per_batch=40)),
     ((320, 200), dict(num_queues=32, unfused_bounces=True)),  # retirement from k_shade, wider grids: other waves-per-queue counts
     ((320, 200), dict(num_queues=32, unfused_primary=True, iters_per_batch=5)),
-    ((320, 200), dict(debug_flags=1024)),                     # two bounces per pass: depths 1+2, 3+4, 5+6, 7
-    ((320, 200), dict(debug_flags=1024, iters_per_batch=7, num_queues=16)),
-    ((320, 200), dict(debug_flags=4096)),                     # one launch per depth (k_bounce) instead of all depths >= 1 in one launch (k_paths)
-    ((640, 361), dict(debug_flags=4096, num_queues=8, iters_per_batch=3)),
-    ((100, 7), dict(debug_flags=4096, num_queues=256)),       # most queues (and most waves' slices) are empty
-    ((320, 200), dict(debug_flags=4096, num_queues=16, blocks_per_cu=1, iters_per_batch=40)),
-    ((320, 200), dict(blocks_per_cu=1, iters_per_batch=40)),  # k_paths: long slices per wave
+    ((320, 200), dict(unfused_bounces=True, num_queues=16, blocks_per_cu=1, iters_per_batch=40)),
+    ((100, 7), dict(unfused_bounces=True, num_queues=256)),   # one dense depth-1 list per queue (BatchInfo::flat), most of them empty
+    ((320, 200), dict(blocks_per_cu=1, iters_per_batch=40)),  # k_paths: long slices per wave, lists of 40 iterations
     ((320, 200), dict(blocks_per_cu=2, num_queues=128, iters_per_batch=2)),  # ... and slices shorter than a wave
-    ((320, 200), dict(debug_flags=128)),                      # the one-group-at-a-time kernel with LDS tables (occupancy experiment)
-    ((320, 201), dict(debug_flags=128, num_queues=32, iters_per_batch=6)),
+    ((320, 201), dict(num_queues=32, iters_per_batch=6, blocks_per_cu=3)),
+    ((320, 200), dict(iters_per_batch=70, num_queues=64)),    # more iterations per batch than a wave has lanes: the list prefix sums take two rounds
 ])
 def test_retirement_records_and_collect_layouts(scene_dir, res, kw):
-    """The retirement path (ptd::RetireBuf: queues own fixed pixel chunks, wave-private record segments, k_collect's LDS
-    tile and iteration-ordered sums) at shapes the default runs do not reach: more chunks per queue than one LDS tile
-    (multi-pass collect), partial last chunks, empty queues, few / many waves per queue, retirement from the unfused
-    shading kernel.  The image must not depend on any of it, bit for bit."""
+    """The retirement path (ptd::RetireBuf: queues own fixed pixel chunks, one exactly-full record region and one depth-1
+    list per (queue, iteration), k_paths' slices of the concatenated lists, k_collect's LDS tile and iteration-ordered sums)
+    at shapes the default runs do not reach: more chunks per queue than one LDS tile (multi-pass collect), partial last
+    chunks, empty queues, few / many waves per queue, retirement from the unfused shading kernel.  The image must not
+    depend on any of it, bit for bit."""
     spp = 10
     ref, rst = gpu_render(scene_dir["cornell"], res, spp)
     img, st = gpu_render(scene_dir["cornell"], res, spp, **kw)
@@ -197,14 +191,14 @@ def test_retirement_records_and_collect_layouts(scene_dir, res, kw):
     assert np.array_equal(bits(img), bits(ref)), kw
 
 
-@pytest.mark.parametrize("scene,res,depth", [("sphere", (200, 200), 4), ("stress", (160, 90), 8), ("cornell", (96, 64), 2), ("cornell", (96, 64), 13), ("cornell", (96, 64), 17)])
+@pytest.mark.parametrize("scene,res,depth", [("sphere", (200, 200), 4), ("stress", (160, 90), 8), ("stress_big", (128, 72), 5), ("cornell", (96, 64), 2), ("cornell", (96, 64), 13), ("cornell", (96, 64), 64)])
 def test_all_depths_in_one_launch_on_other_scenes(scene_dir, scene, res, depth):
-    """k_paths (all depths >= 1 in one launch) against the per-depth launches (debug_flags 4096) where the other tests do not
-    go: a scene with misses (sphere.txt: the sky factor applied trace_depth - depth times, per lane), a scene whose tables stay
-    in global memory (the 126-primitive stress scene), the smallest depth (2: one bounce), a depth beyond what its statistics
-    rows were first written for (13), and one beyond its limit (17: falls back to the per-depth launches)."""
+    """k_paths (all depths >= 1 in one launch, no path state in memory) against the unfused per-depth launches (k_intersect +
+    k_shade, path state and hit records through memory at every depth): a scene with misses (sphere.txt: the sky factor applied
+    trace_depth - depth times, per lane), scenes whose tables stay in global memory (subtree scans; the grid walk), the
+    smallest depth (2: one bounce), deeper ones (13; 64 = PT_MAX_DEPTH).  Same image, same rays per depth."""
     spp = 6
-    ref, rst = gpu_render(scene_dir[scene], res, spp, depth=depth, debug_flags=4096)
+    ref, rst = gpu_render(scene_dir[scene], res, spp, depth=depth, unfused_bounces=True)
     img, st = gpu_render(scene_dir[scene], res, spp, depth=depth)
     assert list(st.live_rays[:depth]) == list(rst.live_rays[:depth])
     assert np.array_equal(bits(img), bits(ref))
