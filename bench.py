@@ -17,20 +17,21 @@ reference semantics by tests/test_gpu_arith.py; `modes` reports exact (bit-ident
 from the same process.
 
 Extra objects on the JSON line:
-  roofline       dominant kernel k_bounce (computeIntersections + shadeAndExtendRays + compaction, depths >= 1):
-                 algorithmic bytes (40 B read + 40 B per survivor / 12 B per retired sample written) / HIP-event
-                 time of those launches (events recorded by the library on its own render stream inside the
+  roofline       dominant kernel k_paths (computeIntersections + shadeAndExtendRays + compaction of ALL depths >= 1 in one
+                 launch: persistent lanes, no path state through HBM after depth 0): algorithmic bytes = 40 B read per
+                 depth-1 ray (its path record, once) + 16 B written per path retired by this kernel (its record, once)
+                 / HIP-event time of those launches (events recorded by the library on its own render stream inside the
                  timed region) vs 8 TB/s; `traffic` = HBM bytes per launch from the committed PMC passes
-                 (profiles/dominant_kernel_traffic.json holds bytes PER RAY for this arithmetic mode) scaled by
-                 this run's rays per launch.
-  roofline.traffic_floor  measured in the same call: a kernel that only moves k_bounce's bytes in k_bounce's work distribution
-                 (build/tools/ubench_stream --floor, tools/ubench_stream.hip) on this run's rays per launch — what this traffic can
-                 reach on this box with no computation at all, in us and as a fraction of the 8 TB/s peak in roofline units
+                 (profiles/dominant_kernel_traffic.json holds bytes PER PATH for this arithmetic mode) scaled by this
+                 run's paths per launch.  The kernel is NOT bound by HBM (frac ~ 0.13): see roofline_valu.
   roofline_valu  the kernel's instruction-issue ceiling: its dynamic VALU mix (committed PMC passes, SQ_INSTS_VALU_*
-                 per 64-ray group) priced at the MEASURED issue rates of tools/ubench_valu.hip (profiles/
+                 per 64 rays) priced at the MEASURED issue rates of tools/ubench_valu.hip (profiles/
                  r03_ubench_valu.txt: f32 add / mul / fma 2.3-2.45 SIMD cycles per wave64 instruction, selects /
-                 compares / min / max / integer multiplies 4.2, transcendentals 8.2) against the SIMD cycles this run
-                 spent per group.  Unclassified instructions are priced at the full rate, so `frac` is a lower bound.
+                 compares / min / max / integer multiplies 4.2, transcendentals 8.2) = needed_cycles, against the SIMD
+                 cycles this run spent per 64 rays = spent_cycles.  Unclassified instructions are priced at the full rate,
+                 so `frac` is a lower bound.
+  pipeline       the whole batch (k_primary + k_paths + k_collect): algorithmic HBM bytes per sample, PMC-measured bytes per
+                 sample (profiles/dominant_kernel_traffic.json "pipeline"), and the rate at which this run moved them vs 8 TB/s.
   cpu_baseline   the oracle (kind "port": oracle/pt_oracle.cpp, reference-literal loop, libm math)
                  timed on ONE host thread on a bounded sample of the same workload (rank 0, N=1 only).
   psnr           (N=1 only, outside the timed region) PSNR of 16/64/256/1000-spp prefixes against a 5000-spp
@@ -85,12 +86,21 @@ def cpu_baseline(scene_path: str, seconds_target: float = 15.0) -> dict:
                       f"reference-literal loop, {dt:.1f} s on 1 of {os.cpu_count()} host threads"}
 
 
+PATH_BYTES = 40 + 16           # k_paths: the depth-1 record of a path read once, its retirement record written once
+
+
 def bounce_accounting(st):
-    """Algorithmic bytes and rays of the timed k_bounce launches from the renderer's live-ray statistics."""
+    """Algorithmic bytes, rays and paths of the timed k_paths launches from the renderer's live-ray statistics."""
     live = np.array(st.live_rays[:DEPTH], dtype=np.float64)
-    nxt = np.append(live[1:], 0.0)  # survivors of depth d = live rays of depth d+1 (none after the last depth)
-    alg = float((40 * live[1:] + 40 * nxt[1:] + 12 * (live[1:] - nxt[1:])).sum())
-    return live, alg, float(live[1:].sum())
+    return live, float(PATH_BYTES * live[1]), float(live[1:].sum()), float(live[1])
+
+
+def pipeline_bytes_per_sample(live, samples, iters_per_batch):
+    """Algorithmic HBM bytes per sample of a whole batch: depth 0 writes a 40-B record per survivor or a 16-B record per retiree;
+    k_paths reads the former and writes a 16-B record per path; k_collect reads every record and reads + writes the image
+    (24 B per pixel and batch)."""
+    s1 = live[1] / samples
+    return 40 * s1 + 16 * (1 - s1) + PATH_BYTES * s1 + 16 + 24.0 / max(1, iters_per_batch)
 
 
 def main() -> None:
@@ -189,16 +199,22 @@ def main() -> None:
         dt = float(tmax.item())
 
     st = r.stats()
-    live, alg_bytes, units = bounce_accounting(st)
+    live, alg_bytes, units, paths = bounce_accounting(st)
     isect_s = st.intersect_ms / 1e3
     roofline = roofline_valu = None
+    prof_all = {}
+    ppath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+    if os.path.exists(ppath):
+        try:
+            prof_all = json.load(open(ppath))
+        except Exception:
+            prof_all = {}
+    prof = prof_all.get(args.arith, {})
     if st.intersect_launches > 0 and isect_s > 0:
         timed = live[1:] if st.primary_fused else live  # depths covered by the timed launches
         if st.bounces_fused:
-            # fused bounce kernel, depths >= 1: 40 B path state read per ray; written: 40 B per survivor or
-            # 12 B per retired sample (the hit record of SURVEY §8d's 56 + 104 B never reaches HBM)
-            kernel = "k_bounce (computeIntersections + shadeAndExtendRays + compaction, depths 1..7)"
-            per_unit = "40 B read + 40 B (survivor) / 12 B (retired) written per ray"
+            kernel = "k_paths (computeIntersections + shadeAndExtendRays + compaction, depths 1..7 in one launch)"
+            per_unit = "40 B read per depth-1 ray (its path record, once) + 16 B written per path (its retirement record, once)"
         else:
             kernel = "k_intersect (computeIntersections)"
             alg_bytes = float(ISECT_BYTES_PER_RAY * timed.sum())
@@ -206,39 +222,36 @@ def main() -> None:
             per_unit = "56 B per live ray (24 read + 32 written)"
         achieved = alg_bytes / isect_s / 1e9
         rays_per_launch = units / st.intersect_launches
+        paths_per_launch = paths / st.intersect_launches
         avg_us = isect_s * 1e6 / st.intersect_launches
-        prof = {}
-        ppath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
-        if os.path.exists(ppath):
-            try:
-                prof = json.load(open(ppath)).get(args.arith, {})
-            except Exception:
-                prof = {}
         same_kernel = prof.get("kernel", "").split(" ")[0] == kernel.split(" ")[0]
-        traffic = round(prof["hbm_bytes_per_ray"] * rays_per_launch) if same_kernel and "hbm_bytes_per_ray" in prof else None
+        traffic = round(prof["hbm_bytes_per_path"] * paths_per_launch) if same_kernel and "hbm_bytes_per_path" in prof else None
         roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": (f"profiles/dominant_kernel_traffic.json [{args.arith}]: {prof['hbm_bytes_per_ray']:.1f} B/ray "
-                                       f"(2 x FETCH_SIZE + WRITE_SIZE) x this run's rays per launch") if traffic else None,
+                    "traffic_source": (f"profiles/dominant_kernel_traffic.json [{args.arith}]: {prof['hbm_bytes_per_path']:.1f} B/path "
+                                       f"(2 x FETCH_SIZE + WRITE_SIZE) x this run's paths per launch") if traffic else None,
                     "launches": int(st.intersect_launches), "avg_launch_us": round(avg_us, 3),
                     "algorithmic_bytes_per_launch": round(alg_bytes / st.intersect_launches, 1),
                     "algorithmic_bytes_per_unit": per_unit,
-                    "rays_per_launch": round(rays_per_launch, 1),
+                    "rays_per_launch": round(rays_per_launch, 1), "paths_per_launch": round(paths_per_launch, 1),
                     "depths_timed": "1..7 (depth 0 runs in the fused primary kernel)" if st.primary_fused else "0..7",
-                    "live_rays_per_sample": round(float(live.sum()) / max(1, st.samples), 4)}
-        roofline["frac_56B"] = round(ISECT_BYTES_PER_RAY * units / isect_s / 1e9 / HBM_PEAK_GBS, 4)  # SURVEY §8(d)'s strict 56 B per live ray
+                    "live_rays_per_sample": round(float(live.sum()) / max(1, st.samples), 4),
+                    "note": "the fused kernel keeps path state on chip: it is bound by instruction issue, not by HBM (roofline_valu); "
+                            "SURVEY 8(d)'s 56 B per live ray describes the unfused k_intersect (bench.py --unfused-bounces)"}
+        roofline["frac_56B"] = round(ISECT_BYTES_PER_RAY * units / isect_s / 1e9 / HBM_PEAK_GBS, 4)  # as if every traced ray moved SURVEY 8(d)'s 56 B
         if same_kernel and "valu_ceiling_simd_cycles_per_group" in prof:
-            # instruction-issue ceiling: SIMD cycles the measured mix needs per group vs SIMD cycles spent per group
+            # instruction-issue ceiling: SIMD cycles the measured mix needs per 64 rays vs SIMD cycles spent per 64 rays
             groups_per_simd = rays_per_launch / 64.0 / (st.num_cus * SIMDS_PER_CU)
             clock = (prof.get("shader_clock_ghz") or 2.1) * 1e9
             spent = avg_us * 1e-6 * clock / groups_per_simd
             need = prof["valu_ceiling_simd_cycles_per_group"]
             roofline_valu = {"bound": "valu", "kernel": kernel.split(" ")[0],
-                             "valu_per_64ray_group": prof["valu_per_group"], "salu_per_64ray_group": prof.get("salu_per_group"),
-                             "valu_mix_per_64ray_group": prof.get("valu_mix_per_group"),
-                             "achieved": round(need, 1), "peak": round(spent, 1), "unit": "SIMD cycles per 64-ray group (needed by the VALU mix at measured issue rates / spent)",
+                             "valu_per_64_rays": prof["valu_per_group"], "salu_per_64_rays": prof.get("salu_per_group"),
+                             "valu_mix_per_64_rays": prof.get("valu_mix_per_group"),
+                             "needed_cycles": round(need, 1), "spent_cycles": round(spent, 1),
+                             "unit": "SIMD cycles per 64 rays (needed by the VALU mix at measured issue rates / spent)",
                              "frac": round(need / spent, 4), "shader_clock_ghz_pmc": prof.get("shader_clock_ghz"),
-                             "source": f"profiles/dominant_kernel_traffic.json [{args.arith}] (PMC: SQ_INSTS_VALU_* per group) priced with "
+                             "source": f"profiles/dominant_kernel_traffic.json [{args.arith}] (PMC: SQ_INSTS_VALU_* per 64 rays) priced with "
                                        f"profiles/r03_ubench_valu.txt; unclassified instructions at the full rate: frac is a lower bound"}
 
     samples = float(W) * H * args.steps
@@ -266,6 +279,15 @@ def main() -> None:
         "roofline": roofline,
         "roofline_valu": roofline_valu,
     }
+    if st.bounces_fused and st.primary_fused and st.samples > 0:
+        alg_ps = pipeline_bytes_per_sample(live, float(st.samples), int(st.iters_per_batch))
+        pmc_ps = prof.get("pipeline_hbm_bytes_per_sample")
+        out["pipeline"] = {"kernels": "k_primary + k_paths + k_collect (+ k_count_stats)", "algorithmic_bytes_per_sample": round(alg_ps, 2),
+                           "pmc_bytes_per_sample": pmc_ps, "pmc_source": "profiles/dominant_kernel_traffic.json [%s] pipeline_hbm_bytes_per_sample "
+                           "(2 x FETCH_SIZE + WRITE_SIZE summed over the batch's kernels / samples)" % args.arith if pmc_ps else None,
+                           "achieved": round(alg_ps * samples / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(alg_ps * samples / dt / 1e9 / HBM_PEAK_GBS, 4),
+                           "frac_pmc": round(pmc_ps * samples / dt / 1e9 / HBM_PEAK_GBS, 4) if pmc_ps else None}
 
     if rank == 0 and world == 1 and not args.no_extras:
         img = full.cpu().numpy()
@@ -287,38 +309,16 @@ def main() -> None:
             torch.cuda.synchronize()
             d1 = time.perf_counter() - t1
             s1 = rr.stats()
-            _, a1, u1 = bounce_accounting(s1)
+            _, a1, u1, _p1 = bounce_accounting(s1)
             sv = round(W * H * msteps / d1 / 1e6, 3)
             modes[m] = {"value": out["value"] if m == args.arith else sv, "steps": args.steps if m == args.arith else msteps,
                         "steady_value": sv, "steady_steps": msteps,
-                        "k_bounce_us": round(s1.intersect_ms * 1e3 / max(1, s1.intersect_launches), 3),
+                        "k_paths_us": round(s1.intersect_ms * 1e3 / max(1, s1.intersect_launches), 3),
                         "rays_per_launch": round(u1 / max(1, s1.intersect_launches), 1),
                         "hbm_frac": round(a1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None,
                         "hbm_frac_56B": round(ISECT_BYTES_PER_RAY * u1 / (s1.intersect_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if s1.intersect_ms > 0 else None}
             rr.free()
         out["modes"] = modes
-        # ---- the traffic floor of the dominant kernel, measured in this call: a kernel that does nothing but k_bounce's
-        # memory traffic in k_bounce's work distribution (tools/ubench_stream.hip --floor), on this run's rays per launch
-        if roofline and st.bounces_fused:
-            exe = os.path.join(ROOT, "build", "tools", "ubench_stream")
-            floor = None
-            if os.path.exists(exe):
-                try:
-                    import subprocess
-                    # compared with the steady leg of the headline mode (same process, full batches): its rays per launch
-                    leg = modes[args.arith]
-                    line = subprocess.run([exe, "--floor", str(int(leg["rays_per_launch"]))], capture_output=True, text=True, timeout=120).stdout.strip().split("\n")[-1]
-                    f = json.loads(line)
-                    floor_us = float(f["us_per_launch"]) * leg["rays_per_launch"] / f["paths"]  # the benchmark rounds the path count down
-                    alg = roofline["algorithmic_bytes_per_launch"] / roofline["rays_per_launch"] * leg["rays_per_launch"]
-                    floor = {"kernel": "no-work kernel: 3-plane records in, 71 % compacted survivors + 29 % 16-byte records out, 256 queues, atomic append",
-                             "rays_per_launch": leg["rays_per_launch"], "us_per_launch": round(floor_us, 2), "tb_per_s": f["tb_per_s"],
-                             "frac_of_peak_in_roofline_units": round(alg / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                             "k_bounce_steady_us": leg["k_bounce_us"], "k_bounce_steady_frac": leg["hbm_frac"],
-                             "floor_over_k_bounce": round(floor_us / leg["k_bounce_us"], 4) if leg["k_bounce_us"] else None}
-                except Exception as e:  # a missing or failing helper must not break the bench line
-                    floor = {"error": str(e)[:200]}
-            roofline["traffic_floor"] = floor
         # the reference builds WITHOUT -use_fast_math (CMakeLists.txt:26-30): FMA contraction, IEEE divide / sqrt — that is
         # the `fma` mode; quote it beside the headline
         out["value_fma"] = modes["fma"]["steady_value"]

@@ -140,6 +140,19 @@ constexpr int kPrimaryWaves = PT_PRIMARY_WAVES;
 struct f3 {
   float x, y, z;
 };
+// ballot() of the HIP headers goes through an integer compare (v_cndmask 0 / 1 + v_cmp per call when the predicate already
+// sits in a scalar register pair); the builtin takes the predicate as it is.
+PT_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// mask * 2 + bit in ONE instruction: v_addc_co_u32 takes the predicate as its carry-in (instead of v_mov + v_cndmask + v_or
+// per box test).  The bits end up in reverse order of the pushes.
+PT_DEV uint32_t push_bit(uint32_t m, bool bit) {
+  uint32_t r;
+  unsigned long long carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(ballot(bit)));
+  return r;
+}
+// number of set bits of m below this lane
+PT_DEV int rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); }
 PT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
 
 // Correctly rounded square root / reciprocal / quotient at about 60 % of the price of the compiler's expansions — same
@@ -160,7 +173,7 @@ PT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
 #endif
 namespace ieee {
 constexpr bool kGuarded = PT_IEEE_FAST != 0;
-PT_DEV bool every_lane(bool ok) { return __ballot(!ok) == 0ull; }
+PT_DEV bool every_lane(bool ok) { return ballot(!ok) == 0ull; }
 // |v| in [2^-60, 2^60]: no v_div_scale case applies to a quotient of two such numbers, and the quotient is a normal number
 PT_DEV bool div_range(float v) { return ((__float_as_uint(v) & 0x7fffffffu) - 0x21800000u) < (0x5d800000u - 0x21800000u); }
 // x in [2^-96, 2^60]: at or above the expansion's pre-scaling threshold, finite; the root is in div_range
@@ -585,7 +598,7 @@ struct Walker {
 // always holds the donor's own ray.  pend: pending subtrees in permute_xor order.
 PT_DEV void steal_step(Walker& w, uint32_t& pend, uint32_t xm, bool idle, unsigned long long I, int* slot,
                        const float4* top, int lane) {
-  const unsigned long long Dn = __ballot(pend != 0);
+  const unsigned long long Dn = ballot(pend != 0);
   if (!Dn) return;
   const int nd = __popcll(Dn), ni = __popcll(I);
   const int drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(Dn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)Dn, 0));
@@ -788,7 +801,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
     const bool pass = valid && (CAM ? Ar<EX>::slab_rel(ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y) : Ar<EX>::slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y));
     if (t_link < 0) {  // leaf entry: type is wave-uniform
-      const unsigned long long m = __ballot(pass);
+      const unsigned long long m = ballot(pass);
       if (m) {
         if (nb + ns + 64 > kCandCap) {
           flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab, tri);
@@ -813,7 +826,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
   // first; lanes without work steal pending (ray, subtree) pairs (steal_step; the donor table lives in the spare row
   // of w.rec).  Candidates are filed under the owner's lane and the primitive tests fetch the ray from the owner's
   // registers o, d as before.
-  if (__ballot(pend != 0)) {
+  if (ballot(pend != 0)) {
     Walker wk{0, 0, lane, o, ri};
     int* slot = reinterpret_cast<int*>(w.rec + 6 * 64);
     const uint32_t xm = octant_mask(ri, top_xor);
@@ -827,7 +840,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
         wk.end = __float_as_int(TB.w);
       }
       const bool idle = wk.cur >= wk.end;
-      const unsigned long long I = __ballot(idle);
+      const unsigned long long I = ballot(idle);
       if (I == ~0ull) break;
       if (__popcll(I) >= kStealMin) steal_step(wk, pend, xm, idle, I, slot, top, lane);
       const bool act = wk.cur < wk.end;
@@ -839,7 +852,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       scan_step<EX>(nodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
       const bool cbox = cand && geoms[aux].type == 1;
       const bool csph = cand && !cbox;
-      const unsigned long long mb = __ballot(cbox), msp = __ballot(csph);
+      const unsigned long long mb = ballot(cbox), msp = ballot(csph);
       if (mb | msp) {
         if (nb + ns + 128 > kCandCap) {
           flush_candidates<CAM, QO, EX>(w, nb, ns, lane, o, d, nodes, geoms, qo_tab, tri);
@@ -1029,7 +1042,7 @@ PT_DEV void shade_bounce_float(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
     s2 = __builtin_amdgcn_sinf(spec ? r3 : r2);
   } else {
     ptmath::sincos_rev(r2, &s2, &c1);
-    if (__ballot(spec)) {  // wave-uniform
+    if (ballot(spec)) {  // wave-uniform
       float s3, c3;
       ptmath::sincos_rev(rev, &sA, &cA);
       ptmath::sincos_rev(r3, &s3, &c3);
@@ -1089,10 +1102,6 @@ PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
   s.d = perturb ? pert : refl;
 }
 
-// __ballot() of the HIP headers goes through an integer compare (v_cndmask 0 / 1 + v_cmp per call when the predicate already
-// sits in a scalar register pair); the builtin takes the predicate as it is.
-PT_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-PT_DEV int rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); }
 
 // Retirement + wave-level compaction of depth 0 (k_primary): a group = 64 pixels of ONE iteration k of queue q.
 //   1. ballots of survivors and retirees; lane 0 reserves room for both with ONE returning 64-bit atomic on cnt[q][k]
@@ -1304,7 +1313,7 @@ PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node*
 template <bool SMALL, int NPAR, bool EX = false, bool LEAN = false>
 PT_DEV void carry_append(Carry<SMALL, NPAR>& c, bool pass, uint32_t leaf, int par, int owner, int lane,
                          const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms, uint32_t gword = 0u) {
-  const unsigned long long m = __ballot(pass);
+  const unsigned long long m = ballot(pass);
   if (!m) return;
   const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
   if (pass) {
@@ -1339,27 +1348,27 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
     // round j every lane that still has candidates files one, so the ballot / rank / ring arithmetic runs once per round
     // (max candidates of a lane, ~3) instead of once per entry (7 for cornell.txt).  The order of the ring entries changes,
     // the set does not, and the closest-hit key is order-independent.
-    auto box = [&](const float4& A, const float4& B) {
-      return CAM ? Ar<EX>::slab_rel(ri, A.x, A.y, A.z, A.w, B.x, B.y) : Ar<EX>::slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y);
-    };
+    // box tests, eight at a time fully unrolled (no loop-carried box registers to rotate); the pass bit is shifted into the mask
+    // by ONE v_addc (push_bit): bit (ntop - 1 - e) of the mask = entry e
     uint32_t mask = 0;
-    float4 A0 = top[0], B0 = top[1];
-    int e = 0;
-    for (; e + 1 < ntop; e += 2) {
-      const float4 A1 = top[2 * e + 2], B1 = top[2 * e + 3];
-      mask |= box(A0, B0) ? (1u << e) : 0u;
-      if (e + 2 < ntop) A0 = top[2 * e + 4], B0 = top[2 * e + 5];
-      mask |= box(A1, B1) ? (2u << e) : 0u;
+    for (int e0 = 0; e0 < ntop; e0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u;
+        if (e < ntop) {
+          const float4 A = top[2 * e], B = top[2 * e + 1];
+          mask = push_bit(mask, CAM ? Ar<EX>::slab_rel(ri, A.x, A.y, A.z, A.w, B.x, B.y) : Ar<EX>::slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y));
+        }
+      }
     }
-    if (e < ntop) mask |= box(A0, B0) ? (1u << e) : 0u;
     mask = valid ? mask : 0u;
     const uint32_t tag = ((uint32_t)par << 6) | (uint32_t)lane;
     while (true) {
-      const unsigned long long m = __ballot(mask != 0u);
+      const unsigned long long m = ballot(mask != 0u);
       if (!m) break;
       const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
       if (mask != 0u) {
-        const int te = __builtin_ctz(mask);
+        const int te = ntop - 1 - __builtin_ctz(mask);
         mask &= mask - 1u;
         const uint32_t leaf = __float_as_uint(reinterpret_cast<const float*>(top)[8 * te + 6]);  // TopEntry::idx
         c.ent[(c.head + c.count + rank) & (kRing - 1)] = (typename Carry<!SUB, NPAR>::Ent)((leaf << 7) | tag);
@@ -1384,7 +1393,7 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
   }
   // Subtrees below the cut (large scenes only): per-lane stackless scans, nearest subtree first, with work stealing
   // (scan_next / steal_step); candidates are filed under the lane that owns the ray, so nothing downstream changes.
-  if (SUB && __ballot(pend != 0)) {
+  if (SUB && ballot(pend != 0)) {
     Walker wk{0, 0, lane, o, ri};
     const uint32_t xm = octant_mask(ri, top_xor);
     pend = permute_xor(pend, xm);
@@ -1397,7 +1406,7 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
         wk.end = __float_as_int(TB.w);
       }
       const bool idle = wk.cur >= wk.end;
-      const unsigned long long I = __ballot(idle);
+      const unsigned long long I = ballot(idle);
       if (I == ~0ull) break;
       if (__popcll(I) >= kStealMin) steal_step(wk, pend, xm, idle, I, c.slot, top, lane);
       const bool act = wk.cur < wk.end;
@@ -1490,8 +1499,8 @@ PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneT
   cr.head = (cr.head + n) & (kCellRing - 1);
   cr.count -= n;
 #ifdef PT_WALK_STATS
-  const int st_seen = __popcll(__ballot(valid && seen)), st_pass = __popcll(__ballot(pass));
-  const int st_box = __popcll(__ballot(valid && !seen && Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn)));
+  const int st_seen = __popcll(ballot(valid && seen)), st_pass = __popcll(ballot(pass));
+  const int st_box = __popcll(ballot(valid && !seen && Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn)));
   PT_STAT(10, st_seen);
   PT_STAT(11, st_pass);
   PT_STAT(12, st_box);
@@ -1581,7 +1590,7 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
   while (true) {
     const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + w.own) + 1]) + slack;
     w.on = w.on && !(w.te > bt) && !(w.te > w.t_end);
-    const unsigned long long M = __ballot(w.on);
+    const unsigned long long M = ballot(w.on);
     if (!M) break;
     PT_STAT(1, 1);
     PT_STAT(2, __popcll(M));
@@ -1618,7 +1627,7 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
       const bool now = pre + want <= kCellRing - 64;
       const int take = now ? want : 0;
 #ifdef PT_WALK_STATS
-      const int st_trips = wave_max_stat(take), st_lanes = __popcll(__ballot(take > 0));
+      const int st_trips = wave_max_stat(take), st_lanes = __popcll(ballot(take > 0));
       PT_STAT(3, 1);
       PT_STAT(8, st_trips);
       PT_STAT(9, st_lanes);
@@ -1627,10 +1636,10 @@ PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& 
       for (int j = 0; j < take; ++j) cr.ent[(base + j) & (kCellRing - 1)] = ((it + (uint32_t)j) << 10) | tag;
       it += (uint32_t)take;
       // the lanes that filed are a prefix of the lanes (pre grows with the lane index): the last one knows the sum
-      const unsigned long long nm = __ballot(now);
+      const unsigned long long nm = ballot(now);
       if (nm) cr.count += __builtin_amdgcn_readlane(pre + want, 63 - __builtin_clzll(nm));
       while (cr.count >= 64) grid_filter<NPAR, EX>(c, cr, 64, sc, lane, nodes, geoms);
-      if (!__ballot(it != se.y)) break;  // the usual case: every list went in at once — no second pass to find that out
+      if (!ballot(it != se.y)) break;  // the usual case: every list went in at once — no second pass to find that out
     }
     // next cell: through the nearest boundary
     w.te = __builtin_fminf(__builtin_fminf(w.tx, w.ty), w.tz);
@@ -1804,7 +1813,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
     // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
     // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
-    const bool near_scene = __ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+    const bool near_scene = ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
                                                    sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
     if constexpr (RING) {
       const int par = it & 1;
@@ -1904,14 +1913,6 @@ PT_DEV void fetch_record_to_lds(const void* b0, const void* b1, const void* b2, 
       : [base] "s"(lds_base), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [o16] "v"(off16), [o8] "v"(off8)
       : "memory", "scc");
 }
-// mask * 2 + bit in ONE instruction: v_addc_co_u32 takes the predicate as its carry-in (instead of v_mov + v_cndmask + v_or
-// per box test).  The bits end up in reverse order of the pushes.
-PT_DEV uint32_t push_bit(uint32_t m, bool bit) {
-  uint32_t r;
-  unsigned long long carry_out;
-  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(ballot(bit)));
-  return r;
-}
 // Per-wave LDS of k_paths: closest-hit keys, winner records, the candidate ring (32-bit entries: leaf | geom << 8 | owner lane
 // << 16 — the geom index rides along, so a chunk does not go through nodes[leaf]) and the running totals.  The rays are NOT
 // kept in LDS: the lanes are persistent, a chunk fetches a candidate's ray from its owner's registers (ds_bpermute).
@@ -1996,13 +1997,13 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
 //         per-lane mark would need cross-lane bookkeeping): all live lanes are searched and shaded in every round.
 //         The grid walk's rings leave no LDS for refill slots (three workgroups per CU with them: measured 17-22 % slower than
 //         the per-depth kernel it replaces), and its rounds take tens of microseconds: the next record of a lane waits in
-//         REGISTERS there, loaded a round ahead by ordinary loads (five waves per SIMD at the price of ~40 B / lane of scratch:
-//         measured faster than four without; prefetching only origin and direction and loading the rest on demand: slower).
+//         REGISTERS there, loaded a round ahead by ordinary loads (waves per SIMD: see PT_PATHS_GRID_WAVES; prefetching only origin
+//         and direction and loading the rest on demand: slower).
 #ifndef PT_PATHS_SCAN_WAVES
 #define PT_PATHS_SCAN_WAVES 5
 #endif
-#ifndef PT_PATHS_GRID_WAVES
-#define PT_PATHS_GRID_WAVES 5
+#ifndef PT_PATHS_GRID_WAVES  // measured in-box, 1000 random objects / C5, Msamples/s at 4 | 5 waves: fast 4549 / 3699 | 3686 / 2817 (the fast build's
+#define PT_PATHS_GRID_WAVES (PT_ARITH == 2 ? 4 : 5)  // 40 B / lane of scratch land in its walk loop), exact 3995 / 3251 | 4316 / 3441
 #endif
 // LDS of a wave's per-iteration tables (k_paths): fill[K] and pre[K + 1]
 __host__ __device__ inline int paths_fill_wave_bytes(const SceneTables& sc) { return ((2 * sc.max_batch_iters + 1) * 4 + 15) & ~15; }

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """Per-mode figures of the dominant kernel from the PMC passes of tools/pmc_passes.sh, written to
 profiles/dominant_kernel_traffic.json[MODE] for bench.py (roofline.traffic, roofline_valu):
-  hbm_bytes_per_ray   (2 x FETCH_SIZE + WRITE_SIZE) / rays per launch.  Corrected as MI355X_MICROARCH.md §HBM prescribes for
+  hbm_bytes_per_path  (2 x FETCH_SIZE + WRITE_SIZE) / depth-1 paths per launch (k_paths moves a path's bytes once, however many
+                      rays it traces; hbm_bytes_per_ray = the same per traced ray).  Corrected as MI355X_MICROARCH.md §HBM prescribes for
                       gfx950: FETCH_SIZE counts 128-B read requests at 64 B (calibrated on this workload: unfused depth-0
                       k_intersect reads exactly 24 B/ray -> ratio 1.985); WRITE_SIZE is exact.  Units: KiB per dispatch.
-  valu_per_group      SQ_INSTS_VALU / 64-ray groups per launch (salu_per_group likewise)
+  pipeline_hbm_bytes_per_sample
+                      the same sum over ALL kernels of a batch (k_primary, k_paths, k_collect, k_count_stats) / samples per batch
+  valu_per_group      SQ_INSTS_VALU / (rays per launch / 64) (salu_per_group likewise)
   valu_busy_frac      SQ_ACTIVE_INST_VALU (quad-cycles, summed over waves) x 4 / (SIMDs x kernel cycles), kernel cycles =
                       SQ_BUSY_CYCLES / shader engines
   shader_clock_ghz    kernel cycles / kernel duration from the kernel trace of the same pass
@@ -79,6 +82,7 @@ def valu_mix(mean, rays):
 
 line = json.loads(open(os.path.join(d, "pass1.json")).read().strip().split("\n")[-1])
 rays = line["roofline"]["rays_per_launch"] if line.get("roofline") else None
+paths = line["roofline"].get("paths_per_launch", rays) if line.get("roofline") else None
 if rays is None:  # passes run with --no-kernel-events: derive from the statistics in config
     raise SystemExit("pass1.json has no roofline object; run the passes with kernel events enabled")
 cus = line["config"]["cus"]
@@ -86,8 +90,11 @@ fetch, write = mean["FETCH_SIZE"] * 1024, mean["WRITE_SIZE"] * 1024
 cycles = mean["SQ_BUSY_CYCLES"] / 32.0  # 32 shader engines report
 out = {"kernel": kern, "dispatches": len(vals["FETCH_SIZE"]), "rays_per_launch": rays,
        "fetch_size_bytes_raw": round(fetch), "write_size_bytes": round(write),
+       "paths_per_launch": paths,
        "hbm_bytes_per_launch": round(2 * fetch + write), "hbm_bytes_per_ray": round((2 * fetch + write) / rays, 2),
+       "hbm_bytes_per_path": round((2 * fetch + write) / paths, 2),
        "algorithmic_bytes_per_ray": round(line["roofline"]["algorithmic_bytes_per_launch"] / rays, 2),
+       "algorithmic_bytes_per_path": round(line["roofline"]["algorithmic_bytes_per_launch"] / paths, 2),
        "valu_per_group": round(mean["SQ_INSTS_VALU"] / (rays / 64), 1), "salu_per_group": round(mean["SQ_INSTS_SALU"] / (rays / 64), 1),
        "lds_per_group": round(mean["SQ_INSTS_LDS"] / (rays / 64), 1),
        "valu_busy_frac": round(mean["SQ_ACTIVE_INST_VALU"] * 4 / (cus * 4 * cycles), 4),
@@ -97,6 +104,27 @@ out = {"kernel": kern, "dispatches": len(vals["FETCH_SIZE"]), "rays_per_launch":
        **valu_mix(mean, rays),
        "avg_launch_us_under_pmc": round(sum(dur) / len(dur) / 1e3, 1) if dur else None,
        "note": "PMC passes of `bench.py --arith %s` (tools/pmc_passes.sh); per-ray figures are scaled by a run's own rays per launch in bench.py" % mode}
+# whole batch: every kernel's HBM bytes, per sample (FETCH_SIZE / WRITE_SIZE passes; one k_primary dispatch per batch)
+tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+batches = 0
+for f in sorted(glob.glob(os.path.join(d, "pass*", "p_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] in tot and "ptk::" in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "FETCH_SIZE" and "k_primary" in r["Kernel_Name"]:
+                batches += 1
+# (dispatches are reported once per XCD instance of the counter: count distinct dispatch ids instead)
+ids = set()
+for f in sorted(glob.glob(os.path.join(d, "pass*", "p_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE" and "k_primary" in r["Kernel_Name"]:
+            ids.add((f, r["Dispatch_Id"]))
+batches = len(ids)
+if batches:
+    k_iters = line["config"]["iters_per_batch"]
+    samples_per_batch = 1920 * 1080 * k_iters
+    out["pipeline_hbm_bytes_per_sample"] = round((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / batches / samples_per_batch, 2)
+    out["pipeline_batches"] = batches
 print(json.dumps(out, indent=1))
 path = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
 try:

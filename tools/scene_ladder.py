@@ -40,7 +40,7 @@ for size in args.sizes.split(","):
                 best = max(best, res[0] * res[1] * args.spp / dt / 1e6)
                 img = r.readback(); st = r.stats(); r.free()
             imgs.append(img)
-            line += f" | {arith} flags {flags}{' grid' if st.grid_cells else ''}: {best:7.0f}"
+            line += f" | {arith} flags {flags}{' grid %d cells' % st.grid_cells if st.grid_cells else ''}: {best:7.0f}"
         if len(imgs) > 1:
             line += " eq" if all(np.array_equal(imgs[0].view(np.uint32), x.view(np.uint32)) for x in imgs[1:]) else " IMAGES DIFFER"
     print(line, flush=True)
