@@ -133,6 +133,9 @@ struct PtContext {
   double isect_ms = 0, render_ms = 0;
   int64_t isect_launches = 0;
   int64_t samples = 0;
+  // A batch that failed half-way (a launch or an event call returned an error) leaves counters and record regions in an
+  // undefined state: the context refuses further renders instead of appending past them.
+  bool failed = false;
 };
 
 namespace {
@@ -1134,8 +1137,12 @@ int pt_ctx_render(PtContext* c, int iter_first, int iter_count) {
   if (get_events(g, &ev)) return -1;
   HIP_OK(hipEventRecord(ev.a, g.stream));
   const int end = iter_first + iter_count;
+  if (g.failed) return fail("pt_render: an earlier batch of this context failed (%s); free it and create a new one", g_err.c_str());
   for (int it = iter_first; it < end; it += g.K)
-    if (run_batch(g, it, std::min(g.K, end - it))) return -1;
+    if (run_batch(g, it, std::min(g.K, end - it))) {
+      g.failed = true;
+      return -1;
+    }
   HIP_OK(hipEventRecord(ev.b, g.stream));
   g.pending_render.push_back(ev);
   return 0;
@@ -1348,6 +1355,19 @@ int pt_stage_intersect(int n, const float* origin, const float* dir, float* t, f
   if (need(g_default, "pt_stage_intersect")) return -1;
   Ctx& g = *g_default;
   if (n <= 0) return 0;
+  if (g.tight_leaves > 0) {
+    // the tightened sphere boxes of a large scene are sized for ray origins inside the scene bounds or at the camera
+    // (sphere_tight_box): rays from elsewhere could lose grazing hits, so they are refused rather than traced differently
+    double olo[3], ohi[3];
+    origin_region(g.root_min, g.root_max, g.cam.position, olo, ohi);
+    for (int i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a) {
+        const float v = origin[(size_t)a * n + i];
+        if (!(v >= olo[a] && v <= ohi[a]))
+          return fail("pt_stage_intersect: ray %d starts outside the scene bounds (this scene's sphere leaves are tightened for origins inside them; "
+                      "PtOptions.debug_flags 2048 keeps the reference's boxes)", i);
+      }
+  }
   HIP_OK(hipSetDevice(g.device));
   Scratch sc;
   ptd::Queues qs = single_queue(g, n);

@@ -131,9 +131,11 @@ PT_DEV int wave_max_stat(int v) {
 #define PT_STEAL_MIN 16
 #endif
 constexpr int kStealMin = PT_STEAL_MIN;  // idle lanes needed before a work-stealing step is run (65: never)
-// Waves per SIMD the depth-0 kernel is compiled for (__launch_bounds__ second argument).
+// Waves per SIMD the depth-0 kernel is compiled for (__launch_bounds__ second argument).  5: the camera ring's 5.9 KB per wave
+// fit five workgroups per CU; in-box, Msamples/s at 4 | 5 | 6: fast 22.5 k | 22.5 k (95 VGPRs either way) | 21.0 k (88 B / lane of
+// scratch), fma 17.27 k | 17.45 k, exact 15.29 k | 15.63 k (97 VGPRs at 4; 95 + 20 B / lane of scratch at 5).
 #ifndef PT_PRIMARY_WAVES
-#define PT_PRIMARY_WAVES 4
+#define PT_PRIMARY_WAVES 5
 #endif
 constexpr int kPrimaryWaves = PT_PRIMARY_WAVES;
 
@@ -174,10 +176,12 @@ PT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
 namespace ieee {
 constexpr bool kGuarded = PT_IEEE_FAST != 0;
 PT_DEV bool every_lane(bool ok) { return ballot(!ok) == 0ull; }
-// |v| in [2^-60, 2^60]: no v_div_scale case applies to a quotient of two such numbers, and the quotient is a normal number
-PT_DEV bool div_range(float v) { return ((__float_as_uint(v) & 0x7fffffffu) - 0x21800000u) < (0x5d800000u - 0x21800000u); }
-// x in [2^-96, 2^60]: at or above the expansion's pre-scaling threshold, finite; the root is in div_range
-PT_DEV bool sqrt_range(float x) { return (__float_as_uint(x) - 0x0f800000u) < (0x5d800000u - 0x0f800000u); }
+// |v| in [2^-47, 2^47): the exponents of numerator and denominator differ by less than 96, so v_div_scale leaves both as they
+// are (VCC = 0, v_div_fmas is a plain FMA) and the quotient is a normal number — by construction, not only by test (round 3's
+// [2^-60, 2^60] relied on the scaled path giving the same result, which the device self-check confirmed but nothing proved)
+PT_DEV bool div_range(float v) { return ((__float_as_uint(v) & 0x7fffffffu) - 0x28000000u) < (0x57000000u - 0x28000000u); }
+// x in [2^-94, 2^60): above the expansion's pre-scaling threshold (2^-96), finite; the root lies in [2^-47, 2^30), inside div_range
+PT_DEV bool sqrt_range(float x) { return (__float_as_uint(x) - 0x10800000u) < (0x5d800000u - 0x10800000u); }
 PT_DEV float sqrt_core(float x) {
 #pragma clang fp contract(off)
   const float s = __builtin_amdgcn_sqrtf(x);
@@ -1227,17 +1231,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, i
 // filled up in between).  Order of evaluation still does not matter: the (t, leaf) key minimum is the
 // reference's choice.
 constexpr int kRing = 128;  // ring entries per wave (power of two; <= 63 pending + <= 64 appended at once)
-// SMALL: the LDS-table kernels (every leaf is one of <= 32 top entries, so leaf indices are < 64): 16-bit ring entries and
-// no work-stealing table — 7424 B per wave instead of 7936, which is what lets a fifth workgroup of k_bounce fit a CU.
-// NPAR: 2 = keys / records / rays double-buffered by group parity (k_bounce: a group is shaded while the next one is
-// searched); 1 = one group at a time (k_bounce_big).
+// SMALL: the primary kernel's ring for LDS-table scenes (every leaf is one of <= 32 top entries, so leaf indices are < 64; every
+// ray starts at the camera): 16-bit ring entries, no work-stealing table, and only the rays' DIRECTIONS kept — 5888 B per
+// wave, which lets a fifth workgroup of k_primary fit a CU.
+// NPAR: 2 = keys / records / rays double-buffered by group parity (k_primary's ring: a group is shaded while the next one is
+// searched); 1 = one group at a time (k_paths modes 1 and 2, k_primary on the grid).
 template <bool SMALL, int NPAR = 2>
 struct Carry {
   using Ent = typename std::conditional<SMALL, uint16_t, uint32_t>::type;
   unsigned long long* best;  // [NPAR][64]
   float* rec;                // [NPAR][6][64]  normal xyz, point xyz
   Ent* ent;                  // [kRing]     (leaf << 7) | (parity << 6) | owner lane
-  float* ray;                // [2][6][64]  origin xyz, direction xyz of each lane's ray, by group parity
+  float* ray;                // [NPAR][kRayPlanes][64]  (origin xyz,) direction xyz of each lane's ray, by group parity
+  f3 cam_o;                  // SMALL: the origin of every ray (wave-uniform)
+  static constexpr int kRayPlanes = SMALL ? 3 : 6;
   int* slot;                 // [64]        scratch of the work-stealing step (carry_search); not SMALL only
   uint32_t* gix;             // [kRing]     LEAN chunks (grid walk) only: geom index | primitive type << 30 of each ring entry
   const float* qo_tab;       // QO chunks (primary rays) only: the camera position in every geom's object space, [geom][3]
@@ -1247,7 +1254,7 @@ struct Carry {
 };
 template <bool SMALL, int NPAR = 2>
 __host__ __device__ constexpr int carry_bytes() {
-  return NPAR * 64 * 8 + NPAR * 6 * 64 * 4 + kRing * (SMALL ? 2 : 4) + NPAR * 6 * 64 * 4 + (SMALL ? 0 : 64 * 4);
+  return NPAR * 64 * 8 + NPAR * 6 * 64 * 4 + kRing * (SMALL ? 2 : 4) + NPAR * (SMALL ? 3 : 6) * 64 * 4 + (SMALL ? 0 : 64 * 4);
 }
 template <bool SMALL, int NPAR = 2>
 PT_DEV Carry<SMALL, NPAR> carry_init(char* base) {
@@ -1255,8 +1262,10 @@ PT_DEV Carry<SMALL, NPAR> carry_init(char* base) {
   c.best = reinterpret_cast<unsigned long long*>(base);
   c.rec = reinterpret_cast<float*>(base + NPAR * 64 * 8);
   c.ray = reinterpret_cast<float*>(base + NPAR * 64 * 8 + NPAR * 6 * 64 * 4);
-  c.ent = reinterpret_cast<typename Carry<SMALL, NPAR>::Ent*>(base + NPAR * 64 * 8 + 2 * NPAR * 6 * 64 * 4);
-  c.slot = reinterpret_cast<int*>(base + NPAR * 64 * 8 + 2 * NPAR * 6 * 64 * 4 + kRing * 4);
+  constexpr int ray_bytes = NPAR * Carry<SMALL, NPAR>::kRayPlanes * 64 * 4;
+  c.ent = reinterpret_cast<typename Carry<SMALL, NPAR>::Ent*>(base + NPAR * 64 * 8 + NPAR * 6 * 64 * 4 + ray_bytes);
+  c.slot = reinterpret_cast<int*>(base + NPAR * 64 * 8 + NPAR * 6 * 64 * 4 + ray_bytes + kRing * 4);
+  c.cam_o = mk(0.f, 0.f, 0.f);
   c.head = c.count = c.appended = c.processed = 0;
   c.debug = 0;
   c.gix = nullptr;
@@ -1279,9 +1288,10 @@ PT_DEV void carry_chunk(Carry<SMALL, NPAR>& c, int n, int lane, const ptd::Node*
   const int src = (int)(entry & 63u);
   const int par = (int)((entry >> 6) & 1u);
   const uint32_t leaf = entry >> 7;
-  const float* ray = c.ray + par * 6 * 64 + src;
-  const f3 ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
-  const f3 rd = mk(ray[3 * 64], ray[4 * 64], ray[5 * 64]);
+  constexpr int RP = Carry<SMALL, NPAR>::kRayPlanes;
+  const float* ray = c.ray + par * RP * 64 + src;
+  const f3 ro = SMALL ? c.cam_o : mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
+  const f3 rd = mk(ray[(RP - 3) * 64], ray[(RP - 2) * 64], ray[(RP - 1) * 64]);
   const uint32_t gw = LEAN ? c.gix[idx] : 0u;
   const int gi = valid ? (LEAN ? (int)(gw & 0x3fffffffu) : nodes[leaf].geom) : 0;
   const ptd::Geom* G = geoms + gi;
@@ -1335,12 +1345,13 @@ template <bool SUB, int NPAR, bool CAM = false, bool EX = false>
 PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, const ptd::Node* __restrict__ nodes,
                          const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par, float cull,
                          unsigned long long top_xor) {
-  static_assert(!(CAM && SUB), "camera-relative search: LDS-table scenes only");
+  static_assert(CAM == !SUB, "the top-list-only form is the primary kernel's camera ring (Carry<true>: origins not stored); subtree scans take any origin");
   const RayInv ri = Ar<EX>::ray_inv(d, o);
   {
-    float* ray = c.ray + par * 6 * 64 + lane;  // this group's rays, read back by the primitive-test chunks
-    ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
-    ray[3 * 64] = d.x, ray[4 * 64] = d.y, ray[5 * 64] = d.z;
+    constexpr int RP = Carry<!SUB, NPAR>::kRayPlanes;
+    float* ray = c.ray + par * RP * 64 + lane;  // this group's rays, read back by the primitive-test chunks
+    if (RP == 6) ray[0 * 64] = o.x, ray[1 * 64] = o.y, ray[2 * 64] = o.z;
+    ray[(RP - 3) * 64] = d.x, ray[(RP - 2) * 64] = d.y, ray[(RP - 1) * 64] = d.z;
   }
   if (!SUB) {
     // Every top entry is a leaf (the LDS-table kernels): first all box tests — one bit per entry in a per-lane mask, boxes
@@ -1797,6 +1808,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   Carry<true, 2> rc = carry_init<true, 2>(lds + tbl + wib * kWaveBytes);  // RING only (the same bytes as `w` otherwise)
   rc.debug = b.debug;
   rc.qo_tab = cam_qo;
+  rc.cam_o = o;
   int it = 0;
   for (int j = r; j < entries; j += wq, ++it) {
     int k, jj;
@@ -2570,8 +2582,8 @@ __global__ void k_ieee_check(int kind, unsigned long long first, unsigned long l
       float v[4];
       for (int j = 0; j < 4; ++j) {
         const uint32_t h = mix32((uint32_t)n * 4u + (uint32_t)j + mix32(seed + (uint32_t)(n >> 30)));
-        uint32_t e = inside ? 67u + (mix32(h ^ 0x9e3779b9u) % 120u) : (h >> 23) & 255u;  // biased exponent: [2^-60, 2^60) or anything
-        if (inside && (h & 0x1fu) == 0u) e = (h & 0x20u) ? 67u : 186u;                   // the edges of the range more often
+        uint32_t e = inside ? 80u + (mix32(h ^ 0x9e3779b9u) % 94u) : (h >> 23) & 255u;   // biased exponent: [2^-47, 2^47) or anything
+        if (inside && (h & 0x1fu) == 0u) e = (h & 0x20u) ? 80u : 173u;                   // the edges of the range more often
         v[j] = __uint_as_float((h & 0x807fffffu) | (e << 23));
         if (!inside && (h & 0x300u) == 0u) v[j] = __uint_as_float(h & 0x80000000u);      // zeros among the unrestricted operands
       }

@@ -164,12 +164,17 @@ def test_init_time_choice_among_structures_never_changes_the_image(oracle, tmp_p
         assert np.array_equal(bits(img), bits(ref)), f"debug_flags {flags}"
 
 
+@pytest.mark.parametrize("layout", ["lattice", "random", "clustered"])
 @pytest.mark.parametrize("arith", ["fma", "fast"])
-def test_tightened_sphere_leaves_do_not_change_fma_and_fast_images(tmp_path, arith):
+def test_tightened_sphere_leaves_do_not_change_fma_and_fast_images(tmp_path, arith, layout):
     """The tightened boxes are sized for the float slop of the sphere test in the reference's arithmetic (x 4); the fma / fast
-    tests round differently but no worse: same image with the reference's boxes (debug_flags 2048), grid and scan."""
+    tests round differently but no worse: same image with the reference's boxes (debug_flags 2048), grid and scan — on the
+    lattice scene and on random / clustered scenes (rotated, non-uniformly scaled spheres; grazing hits at many angles)."""
     res, spp = (320, 200), 4
-    path = scenes.write_scene(scenes.stress_scene_text((12, 12, 10), res=res), str(tmp_path / "s.txt"))
+    text = {"lattice": lambda: scenes.stress_scene_text((12, 12, 10), res=res),
+            "random": lambda: scenes.random_scene_text(31, 1200, res=res),
+            "clustered": lambda: scenes.random_scene_text(32, 1500, res=res, clustered=True)}[layout]()
+    path = scenes.write_scene(text, str(tmp_path / "s.txt"))
     sc = capi.Scene(path, res=res)
     imgs = []
     for flags in (256, 256 | 2048, 512, 512 | 2048):
