@@ -299,7 +299,7 @@ def main() -> None:
         msteps = min(max(args.steps, 200), 1000)
         for m in ("exact", "fma", "fast"):
             rr = make_renderer(True, arith=m)
-            rr.render(1, 200)  # untimed; long enough for the memory the previous leg's renderer released to settle
+            rr.render(1, 200)  # untimed; long enough for the memory the previous leg's renderer released to settle (LABNOTES.md section 6)
             rr.readback_device(tile.data_ptr())
             rr.clear()  # as for the headline run: warm-up and timed steps on the same buffers
             torch.cuda.synchronize()

@@ -306,7 +306,7 @@ void pack_rows(const float m16[16], float out12[12]) {
 // origin; ray origins of the renderer lie in the scene bounds (hit points) or at the camera.  rho^2 = 0.25 + 4 x that sum
 // (safety factor 3.5 on the dominant term), the box is rounded outward and padded by 32 float-eps of M for the slab test's
 // own rounding.  The tightened box lies inside the reference's, so a ray that passes it passes the reference's box and
-// every ancestor (the slab test is monotone under inclusion): the leaves we test are a subset of the
+// every ancestor (the slab test is monotone under inclusion, DESIGN.md §9, LABNOTES.md §9.1): the leaves we test are a subset of the
 // reference's, and the ones we drop return "no hit" there.  Exact mode stays bit-identical (tests: stress scenes and the
 // random-scene fuzz against the oracle, which keeps the reference's boxes); debug_flags 2048 keeps the reference's boxes.
 // pt_stage_intersect on such a scene inherits the assumption about ray origins.
@@ -664,7 +664,7 @@ void use_grid_alt(Ctx& g, size_t i) {
   g.grid_pad = a.pad;
   g.have_grid = true;
 }
-// Grid or BVH scan, and which grid?  All give the same image; which is faster depends on how the
+// Grid or BVH scan, and which grid?  All give the same image (LABNOTES.md section 9.1); which is faster depends on how the
 // primitives are spread and how far rays fly, and no count of references predicted it across lattice, random and clustered
 // scenes — so it is measured: up to 8 iterations of the context's own tile with each (the second of two runs counts), before
 // the first sample is rendered.  Costs a few tens of milliseconds per candidate for a 1080p tile.  debug_flags 256 / 512 skip

@@ -2042,14 +2042,11 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   int tbl = nb_top + nb_mats;
   const ptd::Node* nodes = sc.nodes;
   const ptd::Geom* geoms = sc.geoms;
-  if (MODE == 0) {
-    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+  if (MODE == 0) {  // the geometry records; of the nodes only tword / lmat below are needed (every leaf is a top entry)
     const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
-    stage16(lds + tbl, sc.nodes, nb_nodes);
-    stage16(lds + tbl + nb_nodes, sc.geoms, nb_geoms);
-    nodes = reinterpret_cast<const ptd::Node*>(lds + tbl);
-    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl + nb_nodes);
-    tbl += nb_nodes + nb_geoms;
+    stage16(lds + tbl, sc.geoms, nb_geoms);
+    geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl);
+    tbl += nb_geoms;
   }
   constexpr int wave_bytes = paths_wave_bytes<MODE>();
   constexpr int core_bytes = wave_bytes - paths_extra_bytes<MODE>();
@@ -2437,7 +2434,7 @@ int paths_lds_bytes(const SceneTables& sc, int mode) {
   const int rows = iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 1), common = paths_fill_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + rows;
   const int top = sc.num_top * (int)sizeof(ptd::TopEntry);
   switch (mode) {
-    case 0: return common + top + round16(table_bytes(sc)) + kWavesPerBlock * paths_wave_bytes<0>() + kMaxTop * 4 + 64 * 4;
+    case 0: return common + top + sc.num_geoms * (int)sizeof(ptd::Geom) + kWavesPerBlock * paths_wave_bytes<0>() + kMaxTop * 4 + 64 * 4;
     case 1: return common + top + kWavesPerBlock * paths_wave_bytes<1>();
     default: return common + kWavesPerBlock * paths_wave_bytes<2>();
   }

@@ -1,4 +1,4 @@
-"""The uniform-grid walk on scenes chosen to stress the cell walk itself: flat layouts (one cell
+"""The uniform-grid walk (LABNOTES.md section 9.1) on scenes chosen to stress the cell walk itself: flat layouts (one cell
 along an axis), huge extents, axis-parallel rays that run exactly along cell boundaries, a camera inside the grid, objects
 much larger and much smaller than a cell, no walls at all.  Grid forced (debug_flags 256) against the oracle bit for bit,
 and against the BVH scan (512).  The everyday scenes are in tests/test_gpu_render.py / test_mesh_extension.py."""

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU simulation behind DESIGN.md section 9.1 (no GPU, checker-side only): cells crossed, records met, distinct leaves
+"""CPU simulation behind LABNOTES.md section 9.1 (no GPU, checker-side only): cells crossed, records met, distinct leaves
 and leaf boxes passed per depth-1 ray of the C5 scene for a uniform grid at 1, 2 and 4 cells per primitive, and the longest
 of 64 walks (what a wave's loop runs).  Rays come from the oracle's stage functions.  usage: tools/sim_grid_walk.py [rays]"""
 import os, sys, tempfile, numpy as np

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU simulation behind DESIGN.md section 9 (no GPU, checker-side only): node visits and leaf-box passes of depth-1
+"""CPU simulation behind LABNOTES.md section 9 (no GPU, checker-side only): node visits and leaf-box passes of depth-1
 rays on the C5 scene under different scan orders / cull assumptions, and the loop-step counts of a 64-lane wave with
 and without (ideal) work stealing.  Rays come from the oracle's stage functions; the scan itself is re-implemented
 here in Python on the BVH table of the product's host builder.  usage: tools/sim_scan_orders.py"""
