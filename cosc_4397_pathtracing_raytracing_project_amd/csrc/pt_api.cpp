@@ -34,6 +34,8 @@ constexpr bool kAblateBuild = false;  // release library: pt_init rejects them
 
 std::string g_err;
 constexpr int kGridNodes = 1024;       // scenes from this many BVH nodes on are candidates for the uniform grid (build_grid, choose_traversal)
+constexpr int kTightNodes = 64;        // scenes from this many BVH nodes on test sphere leaves against the ellipsoid's box (sphere_tight_box); the
+                                       // reference's own scenes (cornell.txt: 13 nodes) keep the reference's boxes
 }  // namespace
 int pt_fail(const char* fmt, ...) {  // pt_internal.h: sets pt_last_error(), returns -1
   char buf[1024];
@@ -653,6 +655,7 @@ void plan_launch(Ctx& g) {
   g.grid_isect = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(g.legacy ? ptk::kIntersectLegacy : ptk::kIntersect, t));
   g.grid_shade = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kShade, t));
   g.grid_primary = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
+  g.ret.wq0 = g.grid_primary * ptk::kWavesPerBlock / g.qs.Q;  // the sub-lists' residue count (pt_device.h RetireBuf)
   g.grid_paths = (g.fuse_bounces && g.depth > 1) ? g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPaths, t)) : 0;
 }
 
@@ -863,7 +866,7 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   std::memcpy(g.root_min, ref_nodes[0].bmin, 12);
   std::memcpy(g.root_max, ref_nodes[0].bmax, 12);
   g.tight_leaves = 0;
-  if (g.num_nodes >= kGridNodes && !(opt.debug_flags & 2048)) {
+  if (g.num_nodes >= kTightNodes && !(opt.debug_flags & 2048)) {
     double olo[3], ohi[3];
     origin_region(g.root_min, g.root_max, g.cam.position, olo, ohi);
     g.tight_leaves = tighten_sphere_leaves(nodes, g.geoms, olo, ohi);
@@ -965,8 +968,10 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   if (!g.fuse_bounces && alloc_hitbuf(g, &g.hits, g.stride)) return -1;  // hit records reach HBM only in the unfused form
   {
     const size_t regions = (size_t)Q * g.ret.kmax;
-    if (dalloc(g, &g.ret.rec, regions * g.ret.seg_cap) || dalloc(g, &g.ret.cnt, regions)) return -1;
+    const size_t wq_max = (size_t)g.num_cus * 8 * ptk::kWavesPerBlock / Q;  // waves per queue of the widest k_primary grid
+    if (dalloc(g, &g.ret.rec, regions * g.ret.seg_cap) || dalloc(g, &g.ret.cnt, regions) || dalloc(g, &g.ret.sub, regions * wq_max)) return -1;
     HIP_OK(hipMemset(g.ret.cnt, 0, regions * sizeof(unsigned long long)));  // k_collect re-zeroes them after every batch
+    HIP_OK(hipMemset(g.ret.sub, 0, regions * wq_max * sizeof(unsigned long long)));
   }
   if (dalloc(g, &g.d_image, 3 * (size_t)g.N)) return -1;
   if (dalloc(g, &g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;

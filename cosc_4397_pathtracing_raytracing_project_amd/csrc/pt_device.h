@@ -102,24 +102,31 @@ struct HitBuf {
 // order.  Rounds 1-2 stored each colour at final[k*N + p]: one scattered 16-byte write per sample, each a partially written
 // DRAM line — a third of the bounce kernel's time at K = 25 (round 3 ablation).  Round 3 appended records to segments private
 // to (queue, iteration, wave), each sized for ALL of the queue's pixels: coalesced, but 32 x over-provisioned (27 GB for a
-// 1080p frame).  Now the fit is exact:
+// 1080p frame).  Now the fit is exact and nothing is reserved with atomics:
 //   * a queue owns the SAME pixel chunks in every iteration (Queues, below): region (q, k) has one record slot per pixel of
-//     queue q, seg_cap = nq * 64 of them, and every sample of (q, k) retires exactly once, so the region ends up exactly full;
-//   * depth 0 (k_primary) appends its retirees at the FRONT of region (q, k) and its survivors to the depth-1 list (q, k) — list
-//     (q, k) lives at path index q * cap + k * seg_cap — with ONE 64-bit atomic per 64-sample group on cnt[q][k]
-//     (high word: records appended, low word: survivors appended);
-//   * depths >= 1 (k_paths) run after depth 0 of the whole batch: the survivor counts n_k are final, a wave takes a
-//     contiguous slice [lo, hi) of the queue's concatenated lists and retires exactly the paths it took, so its records
-//     of iteration k go to region (q, k) at (pixels - n_k) + |[0, lo) ∩ list k| onward — consecutive lanes to consecutive
-//     addresses, no global atomics, the positions come from a counter in LDS;
+//     queue q, seg_cap = nq * 64 of them, and the depth-1 list (q, k) — the survivors of depth 0 — lives at path index
+//     q * cap + k * seg_cap, also seg_cap long;
+//   * depth 0 (k_primary): in iteration k wave r of the queue's wq0 waves traces the chunks jj = rho, rho + wq0, ... with
+//     rho = (r + k) mod wq0 (the residue rotates so that chunk counts even out over a batch).  Those are c(rho) chunks, and
+//     off(rho) chunks belong to smaller residues, so SUB-list / SUB-region (q, k, rho) = slots [off(rho) * 64, (off(rho) +
+//     c(rho)) * 64) of list / region (q, k) is the wave's own: it appends survivors to the sub-list and retirees to the front
+//     of the sub-region from counters in its registers, stores at once, and leaves the two counts in sub[q][k][rho];
+//   * depths >= 1 (k_paths) run after depth 0 of the whole batch.  A wave takes a contiguous slice of the queue's concatenated
+//     sub-lists; the record of the path at index i of sub-list (k, rho) goes to slot retirees(k, rho) + i of sub-region
+//     (k, rho): decided when the path is taken, no counters at all.  Every sample of the sub-region's chunks retires exactly
+//     once, so the region ends up exactly full (but for the <= 63 slots of a tile's partial last chunk, which k_collect skips);
 //   * k_collect, one workgroup per queue, reads region (q, k) for k = 0, 1, ... front to back, drops the colours into an LDS
 //     tile indexed by pixel, and adds the tile to the queue's pixels — the reference's summation order.
-// The unfused stage kernels (tests, A/B) append every record at the front through the high word, one atomic per record.
+// The unfused stage kernels (tests, A/B: BatchInfo::flat) append every record at the front of its region through cnt[q][k],
+// one atomic per record, and keep ONE dense depth-1 list per queue.
 struct RetireBuf {
   Word4* rec;               // [Q][kmax][seg_cap]
-  unsigned long long* cnt;  // [Q][kmax]: records appended at the front << 32 | depth-0 survivors appended to list (q, k); zero between batches
+  unsigned long long* sub;  // [Q][kmax][wq0]: retirees << 32 | survivors of depth 0 in sub-region / sub-list (q, k, rho); rewritten by every batch
+  unsigned long long* cnt;  // [Q][kmax]: flat form only — records appended at the front of region (q, k) << 32; zero between batches
   int32_t seg_cap;          // nq * 64: pixels a queue owns (a multiple of 64)
   int32_t kmax;             // iterations per batch the regions are provisioned for
+  int32_t wq0;              // waves per queue of the k_primary launches (the sub-lists' residue count)
+  int32_t pad;
 };
 
 // Work distribution.  Paths live in Q independent queues of capacity `cap`

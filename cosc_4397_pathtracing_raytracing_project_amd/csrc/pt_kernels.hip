@@ -477,16 +477,23 @@ PT_DEV uint32_t path_seed(int k, int pl, const uint32_t* ihash, const SceneTable
 // One queue's regions and counters (pt_device.h RetireBuf).
 struct Retire {
   ptd::Word4* rec;          // region (q, 0); region (q, k) starts k * seg_cap records further
-  unsigned long long* cnt;  // [kmax]: records appended at the front << 32 | depth-0 survivors in list (q, k)
-  int seg_cap;
+  unsigned long long* sub;  // [kmax][wq0]: retirees << 32 | survivors of depth 0 per sub-region / sub-list (q, k, rho)
+  unsigned long long* cnt;  // [kmax]: flat form — records appended at the front of region (q, k) << 32
+  int seg_cap, wq0;
 };
 PT_DEV Retire retire_of(const ptd::RetireBuf& rb, int q) {
   Retire rt;
   rt.rec = rb.rec + (int64_t)q * rb.kmax * rb.seg_cap;
+  rt.sub = rb.sub + (int64_t)q * rb.kmax * rb.wq0;
   rt.cnt = rb.cnt + (int64_t)q * rb.kmax;
-  rt.seg_cap = rb.seg_cap;
+  rt.seg_cap = rb.seg_cap, rt.wq0 = rb.wq0;
   return rt;
 }
+// Sub-list / sub-region (q, k, rho) of a queue with my_nq chunks per iteration dealt to wq0 residues: c(rho) chunks, the first
+// of them off(rho) chunks into list / region (q, k)  (residue rho owns the chunks jj = rho, rho + wq0, ...).
+// (quo = my_nq / wq0, rem = my_nq % wq0, computed once per kernel)
+PT_DEV int sub_chunks(int quo, int rem, int rho) { return quo + (rho < rem ? 1 : 0); }
+PT_DEV int sub_offset(int quo, int rem, int rho) { return rho * quo + min(rho, rem); }
 PT_DEV void retire_store(const Retire& rt, bool dead, int k, int pos, int pl, f3 c) {
 #ifdef PT_ABL_NO_RETIRE  // timing experiment only (wrong images)
   return;
@@ -1107,49 +1114,6 @@ PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
 }
 
 
-// Retirement + wave-level compaction of depth 0 (k_primary): a group = 64 pixels of ONE iteration k of queue q.
-//   1. ballots of survivors and retirees; lane 0 reserves room for both with ONE returning 64-bit atomic on cnt[q][k]
-//      (records << 32 | survivors) — issued before shade_bounce, the stores follow one loop iteration later (Deferred);
-//   2. survivors go to list (q, k) (path index q * cap + k * seg_cap + ...), records to the front of region (q, k).
-// flat (BatchInfo::flat: the consumer is the unfused k_intersect / k_shade pair, which wants ONE dense list per queue): the
-// survivors' position comes from the queue's depth-1 counter instead (a second atomic), the records go the same way.
-struct Reservation {
-  unsigned long long live, dead;
-  unsigned long long base;  // lane 0: record position << 32 | survivor position of the group's first
-};
-PT_DEV Reservation reserve_group(bool alive, bool dead, unsigned long long* cnt_k, int32_t* flat_counter, bool flat, int lane) {
-  Reservation r;
-  r.live = ballot(alive), r.dead = ballot(dead);
-  r.base = 0ull;
-  if (lane == 0 && (r.live | r.dead)) {
-    const unsigned long long nl = (unsigned long long)__popcll(r.live), nd = (unsigned long long)__popcll(r.dead);
-    unsigned long long old = atomicAdd(cnt_k, (nd << 32) | (flat ? 0ull : nl));
-    if (flat && nl) old = (old & 0xffffffff00000000ull) | (uint32_t)atomicAdd(flat_counter, (int)nl);
-    r.base = old;
-  }
-  return r;
-}
-// Deferred emission.  The reservation is a RETURNING global atomic: ~2-3 thousand cycles round trip, far more than the
-// direction sampling it used to hide behind.  The survivors and records of a shaded group therefore wait in registers until
-// the NEXT group's candidate search has run, and are stored then.
-struct Deferred {
-  Reservation res;
-  ShadeIO s;
-  PathTag tag;
-  bool alive, dead;
-  bool any;  // wave-uniform: a shaded group's stores are pending
-};
-PT_DEV void flush_deferred(Deferred& df, int64_t qbase, ptd::PathBuf out, const Retire& rt, const BatchInfo& b) {
-  if (df.any) {
-    const uint32_t lb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)df.res.base);
-    const uint32_t db = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(df.res.base >> 32));
-    const int64_t list = b.flat ? qbase : qbase + (int64_t)df.tag.k * rt.seg_cap;
-    if (df.alive) path_store(out, list + lb + rank_in(df.res.live), df.s.o, df.s.d, df.s.c, df.tag);
-    retire_store(rt, df.dead, df.tag.k, (int)db + rank_in(df.res.dead), df.tag.slot & ((1 << b.slot_shift) - 1), df.s.c);
-  }
-  df.any = false;
-}
-
 __global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
                                                   const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
                                                   ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
@@ -1748,20 +1712,30 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
     w.list = reinterpret_cast<uint32_t*>(base + 64 * 8 + 7 * 64 * 4);
   }
   const int ntop = sc.num_top;
-  const int wave = blockIdx.x * kWavesPerBlock + wib;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wib);  // (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
   const int lane = lane_id();
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const Retire rt = retire_of(ret, q);
-  // the queue's samples, iteration-major: entry j = k * my_nq + jj is chunk q + jj * Q of iteration k (same map as k_generate)
+  // The wave's samples: in iteration k the chunks jj = rho, rho + wq, ... of the queue's my_nq (chunk jj = tile chunk q + jj * Q),
+  // rho = (r + k) mod wq — its own sub-list and sub-region of (q, k) (pt_device.h RetireBuf): positions come from the two
+  // counters below, nothing is reserved with atomics and every store is issued where its group is shaded.
   const QueueShare sh = queue_share(b, qs, q);
   if (r == 0 && lane == 0) cnt0[(size_t)q * qs.cnt_stride] = b.K * sh.my_pixels;
-  const int entries = b.K * sh.my_nq;
   const int64_t qbase = (int64_t)q * qs.cap;
   const float inv_w = 1.0f / (float)cam.res_x;
   const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
-  Deferred df;
-  df.any = false;
-  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];
+  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];  // flat form: the queue's ONE depth-1 list
+  const int quo = sh.my_nq / wq, rem = sh.my_nq % wq;
+  int ck = -1, crho = r == 0 ? wq - 1 : r - 1, nl = 0, nd = 0;  // iteration the counters belong to, its residue (r + ck) mod wq; survivors / retirees of the wave in it so far
+  auto publish = [&]() {  // the finished iteration's counts (also when the wave had no chunk in it: zeros)
+    if (ck >= 0 && lane == 0) rt.sub[ck * rt.wq0 + crho] = ((unsigned long long)(uint32_t)nd << 32) | (uint32_t)nl;
+  };
+  auto next_iteration = [&]() {  // publish, then on to ck + 1
+    publish();
+    nl = nd = 0;
+    ++ck;
+    crho = crho + 1 == wq ? 0 : crho + 1;
+  };
   // shading + retirement + compaction of one group of primary rays from its resolved hit key / record
   auto shade_group = [&](unsigned long long best, const float* rec, bool valid, int k, int pl, int slot, uint32_t phash, f3 d) {
     const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
@@ -1786,14 +1760,24 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
       }
       bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
     }
-    const bool alive = valid && s.alive;
-    df.res = reserve_group(alive, valid && !s.alive, &rt.cnt[k], counter, b.flat != 0, lane);
+    const bool alive = valid && s.alive, dead = valid && !s.alive;
     if (alive) shade_bounce(bo, hn, hp, s);
-    df.s = s;
-    df.tag = PathTag{slot, phash, k};
-    df.alive = alive;
-    df.dead = valid && !s.alive;
-    df.any = true;
+    const unsigned long long live = ballot(alive);
+    const PathTag tag{slot, phash, k};
+    if (b.flat) {  // unfused consumers: one dense list per queue behind an atomic, records appended one by one (test / A-B form)
+      int base = 0;
+      if (live && lane == 0) base = atomicAdd(counter, (int)__popcll(live));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (alive) path_store(out, qbase + base + rank_in(live), s.o, s.d, s.c, tag);
+      retire_append(rt, dead, k, pl, s.c);
+      return;
+    }
+    while (ck < k) next_iteration();  // first group of a new iteration: the previous one's counts are final (iterations without a chunk publish zeros on the way)
+    const int sub0 = k * rt.seg_cap + sub_offset(quo, rem, crho) * 64;  // first slot of sub-list / sub-region (q, k, rho)
+    const unsigned long long deadm = ballot(dead);
+    if (alive) path_store(out, qbase + sub0 + nl + rank_in(live), s.o, s.d, s.c, tag);
+    if (dead) rt.rec[sub0 + nd + rank_in(deadm)] = ptd::Word4{s.c.x, s.c.y, s.c.z, __int_as_float(pl)};
+    nl += (int)__popcll(live), nd += (int)__popcll(deadm);
   };
   // a group between its search and its shading (RING)
   struct {
@@ -1810,55 +1794,53 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   rc.qo_tab = cam_qo;
   rc.cam_o = o;
   int it = 0;
-  for (int j = r; j < entries; j += wq, ++it) {
-    int k, jj;
-    divmod(j, sh.my_nq, sh.inv_my_nq, k, jj);
-    const int pl_raw = (q + jj * qs.Q) * 64 + lane;
-    const bool valid = pl_raw < b.N;
-    const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
-    const int slot = make_slot(b, k, pl);
-    const int p = global_pixel(b, pl);  // global pixel index
-    const uint32_t phash = utilhash((uint32_t)p);
-    float jx = 0.f, jy = 0.f;
-    if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
-    const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
-    // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
-    // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
-    // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
-    const bool near_scene = ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
-                                                   sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-    if constexpr (RING) {
-      const int par = it & 1;
-      rc.best[par * 64 + lane] = kNoHit;
-      if (near_scene) carry_search<false, 2, true, kD0>(rc, cam_top, ntop, nodes, geoms, o, d, valid, lane, par, sc.cull_margin, sc.top_xor);
-      if (pp.any) carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
-      flush_deferred(df, qbase, out, rt, b);
-      if (pp.any) shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
-      pp.d = d, pp.k = k, pp.pl = pl, pp.slot = slot, pp.phash = phash, pp.valid = valid, pp.par = par, pp.mark = rc.appended, pp.any = true;
-    } else {
-      if (GRID) {
-        w.best[lane] = kNoHit;
-        if (near_scene) {
-          grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
-          while (cy.count > 0) carry_chunk<false, 1, kD0, true>(cy, min(64, cy.count), lane, nodes, geoms);
-        }
-      } else if (near_scene) {
-        trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
+  for (int k = 0, rho = r; k < b.K; ++k, rho = rho + 1 == wq ? 0 : rho + 1) {
+    for (int jj = rho; jj < sh.my_nq; jj += wq, ++it) {
+      const int pl_raw = (q + jj * qs.Q) * 64 + lane;
+      const bool valid = pl_raw < b.N;
+      const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
+      const int slot = make_slot(b, k, pl);
+      const int p = global_pixel(b, pl);  // global pixel index
+      const uint32_t phash = utilhash((uint32_t)p);
+      float jx = 0.f, jy = 0.f;
+      if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
+      const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
+      // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
+      // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
+      // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
+      const bool near_scene = ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+                                                     sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
+      if constexpr (RING) {
+        const int par = it & 1;
+        rc.best[par * 64 + lane] = kNoHit;
+        if (near_scene) carry_search<false, 2, true, kD0>(rc, cam_top, ntop, nodes, geoms, o, d, valid, lane, par, sc.cull_margin, sc.top_xor);
+        if (pp.any) carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
+        if (pp.any) shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
+        pp.d = d, pp.k = k, pp.pl = pl, pp.slot = slot, pp.phash = phash, pp.valid = valid, pp.par = par, pp.mark = rc.appended, pp.any = true;
       } else {
-        w.best[lane] = kNoHit;
+        if (GRID) {
+          w.best[lane] = kNoHit;
+          if (near_scene) {
+            grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
+            while (cy.count > 0) carry_chunk<false, 1, kD0, true>(cy, min(64, cy.count), lane, nodes, geoms);
+          }
+        } else if (near_scene) {
+          trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
+        } else {
+          w.best[lane] = kNoHit;
+        }
+        shade_group(w.best[lane], w.rec + lane, valid, k, pl, slot, phash, d);
       }
-      flush_deferred(df, qbase, out, rt, b);  // the previous chunk's survivors (see Deferred)
-      shade_group(w.best[lane], w.rec + lane, valid, k, pl, slot, phash, d);
     }
   }
   if constexpr (RING) {
     if (pp.any) {
       carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);
-      flush_deferred(df, qbase, out, rt, b);
       shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
     }
   }
-  flush_deferred(df, qbase, out, rt, b);
+  if (!b.flat)
+    while (ck < b.K) next_iteration();  // the last iteration's counts, and zeros for trailing iterations without a chunk
 }
 
 // ── ALL depths >= 1 in one launch: persistent lanes (k_paths) ─────────────────────────────────────────────────────────────────
@@ -1889,7 +1871,7 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
 #define PT_PATHS_MIN_READY 32  // fewer resolved lanes than this and candidates pending: run the partial chunk instead of shading a thin group
 #endif
 constexpr int kPathsWaves = PT_PATHS_WAVES, kPathsMinReady = PT_PATHS_MIN_READY;
-constexpr int kSlotBytes = 64 * 16 + 64 * 16 + 64 * 4 + 64 * 4;  // planes 0, 1 (16 B per lane), colour.z, sample id
+constexpr int kSlotBytes = 64 * 16 + 64 * 16 + 64 * 4 + 64 * 4 + 64 * 4;  // planes 0, 1 (16 B per lane), colour.z, sample id, record slot
 typedef float v4f __attribute__((ext_vector_type(4)));
 PT_DEV uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 // memory -> LDS without passing through VGPRs: path record i of a queue (b0 / b1 / b2 = the queue's first record in planes 0,
@@ -2017,9 +1999,6 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
 #ifndef PT_PATHS_GRID_WAVES  // measured in-box, 1000 random objects / C5, Msamples/s at 4 | 5 waves: fast 4549 / 3699 | 3686 / 2817 (the fast build's
 #define PT_PATHS_GRID_WAVES (PT_ARITH == 2 ? 4 : 5)  // 40 B / lane of scratch land in its walk loop), exact 3995 / 3251 | 4316 / 3441
 #endif
-// LDS of a wave's per-iteration tables (k_paths): fill[K] and pre[K + 1]
-__host__ __device__ inline int paths_fill_wave_bytes(const SceneTables& sc) { return ((2 * sc.max_batch_iters + 1) * 4 + 15) & ~15; }
-__host__ __device__ inline int paths_fill_bytes(const SceneTables& sc) { return kWavesPerBlock * paths_fill_wave_bytes(sc); }
 template <int MODE>
 constexpr bool paths_slots_in_lds() { return MODE != 2; }
 template <int MODE>
@@ -2032,7 +2011,7 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PATHS_SCAN_WAVES : PT_PATHS_GRID_WAVES) void k_paths(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
                                                                ptd::PathBuf in, ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw) + paths_fill_bytes(sc);  // the waves' per-iteration tables come first
+  char* lds = reinterpret_cast<char*>(lds_raw);
   const int nb_top = MODE == 2 ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk replaces top list and subtrees
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
@@ -2076,43 +2055,69 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   char* slots = wbase + core_bytes;  // SLOTS: [64] x 16 B, [64] x 16 B, [64] x 4 B, [64] x 4 B
   int* died = reinterpret_cast<int*>(slots + (SLOTS ? kSlotBytes : 0));  // [64]: paths of this wave retired AT depth d (statistics; PT_MAX_DEPTH = 64)
   const int ntop = sc.num_top;
-  const int wave = blockIdx.x * kWavesPerBlock + wib;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wib);  // (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
   const int lane = lane_id();
   died[lane] = 0;
   const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   const Retire rt = retire_of(ret, q);
   const size_t per_depth = (size_t)qs.Q * qs.cnt_stride;
   const int64_t qbase = (int64_t)q * qs.cap;
-  // The queue's depth-1 rays: one list per iteration k (k_primary's survivors; n_k = the low word of cnt[q][k], final before
-  // this launch).  pre[k] = rays in the lists before list k; the wave's slice [lo, hi) of the concatenated lists; fill[k] = where
-  // the wave's next record of iteration k goes in region (q, k): behind depth 0's (pixels - n_k) and behind the records of the
-  // rays of list k that lie before the slice (they belong to the waves before this one, which retire exactly those).
-  int* fill = reinterpret_cast<int*>(reinterpret_cast<char*>(lds_raw) + wib * paths_fill_wave_bytes(sc));  // [K]
-  int* pre = fill + sc.max_batch_iters;                                                                    // [K + 1]
+  // The queue's depth-1 rays: k_primary's sub-lists (k, rho), e = k * wq0 + rho, concatenated in that order (their survivor
+  // counts — the low words of sub[e] — are final before this launch).  The wave takes the slice [lo, hi) of global ranks and
+  // walks it front to back with a cursor: the sub-list the next rank lies in, where that sub-list starts in the queue's path
+  // region, and where the records of its paths go — slot retirees(e) + i of sub-region e for the path at index i (RetireBuf).
+  const int wq0 = rt.wq0, ne = b.K * wq0;
+  const int my_nq = queue_share(b, qs, q).my_nq, quo = my_nq / wq0, rem = my_nq % wq0;
+  auto count_of = [&](int e) { return e < ne ? (int)(uint32_t)rt.sub[e] : 0; };
   int total = 0;
-  for (int k0 = 0; k0 < b.K; k0 += 64) {
-    const int kk = k0 + lane;
-    const int n = kk < b.K ? (int)(uint32_t)rt.cnt[kk] : 0;
+  for (int e0 = 0; e0 < ne; e0 += 64) {
     int sum;
-    const int before = wave_prefix6(n, sum);
-    if (kk < b.K) pre[kk] = total + before;
+    (void)wave_prefix6(count_of(e0 + lane), sum);
     total += sum;
   }
-  if (lane == 0) pre[b.K] = total;
   const int per = (total + wq - 1) / wq;
   const int lo = min(r * per, total), hi = min(lo + per, total);
-  const int my_pixels = queue_share(b, qs, q).my_pixels;
-  for (int kk = lane; kk < b.K; kk += 64) {
-    const int n = pre[kk + 1] - pre[kk];
-    fill[kk] = (my_pixels - n) + min(max(lo - pre[kk], 0), n);
-  }
   if (r == 0 && lane == 0) cnt[per_depth * 1 + (size_t)q * qs.cnt_stride] = total;  // statistics: rays traced at depth 1
-  int kc = 0;  // wave-uniform: a list at or before the one rank `streamed` lies in
-  // path index (inside the queue's region) of the ray of global rank i
-  auto locate = [&](int i) {
-    int kk = kc;
-    while (i >= pre[kk + 1]) ++kk;  // (i < total = pre[K]; empty lists are stepped over)
-    return kk * rt.seg_cap + (i - pre[kk]);
+  int ce = ne, ck = 0, crho = 0, cstart = total, ccnt = 0, clist = 0, crec = 0;  // cursor (wave-uniform): sub-list e = ck * wq0 + crho; an empty slice leaves it at the end
+  auto cursor_bases = [&]() {
+    const int sub0 = ck * rt.seg_cap + sub_offset(quo, rem, crho) * 64;
+    clist = sub0;
+    crec = sub0 + __builtin_amdgcn_readfirstlane((int)(uint32_t)(rt.sub[min(ce, ne - 1)] >> 32));
+  };
+  if (lo < hi) {
+    int cum = 0;
+    for (int e0 = 0; e0 < ne; e0 += 64) {
+      const int n = count_of(e0 + lane);
+      int sum;
+      const int before = wave_prefix6(n, sum);
+      const unsigned long long here = ballot(n > 0 && cum + before <= lo && lo < cum + before + n);
+      if (here) {
+        const int l = __builtin_ctzll(here);
+        ce = e0 + l, cstart = cum + __builtin_amdgcn_readlane(before, l), ccnt = __builtin_amdgcn_readlane(n, l);
+        ck = ce / wq0, crho = ce - ck * wq0;
+        break;
+      }
+      cum += sum;
+    }
+    cursor_bases();
+  }
+  // Path index (inside the queue's region) and record slot (inside the queue's regions) of the rays of global rank `rank`, for
+  // the lanes that `want` one; ranks only grow, so the cursor only moves forward.  Wave-uniform control flow.
+  auto assign = [&](bool want, int rank, int& at, int& rs) {
+    bool pending = want;
+    while (true) {
+      const bool in = pending && rank < cstart + ccnt;
+      if (in) at = clist + (rank - cstart), rs = crec + (rank - cstart);
+      pending = pending && !in;
+      if (!ballot(pending) || ce >= ne) break;
+      cstart += ccnt;  // on to the next sub-list that holds anything
+      do {
+        ++ce;
+        if (++crho == wq0) crho = 0, ++ck;
+        ccnt = __builtin_amdgcn_readfirstlane(count_of(ce));
+      } while (ce < ne && ccnt == 0);
+      cursor_bases();
+    }
   };
   const uint32_t s_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(slots));
   const uint32_t s16 = s_base + (uint32_t)lane * 16u, s4 = s_base + 2048u + (uint32_t)lane * 4u;
@@ -2121,21 +2126,24 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const float* in2 = uniform_ptr(reinterpret_cast<const float*>(in.r + 2 * in.stride) + 2 * qbase);
   PathRec nx;  // !SLOTS: the lane's next record, in registers
   nx.o = nx.d = nx.c = mk(0.f, 0.f, 0.f), nx.tag = PathTag{0, 0u, 0};
-  auto fetch = [&](int i) {
-    const int at = locate(i);
-    if constexpr (SLOTS) fetch_record_to_lds(in0, in1, in2, at, s_base);
-    else nx = path_load(in, qbase + at);
+  int nx_rs = 0;  // !SLOTS: ... and its record slot
+  int* slot_rs = reinterpret_cast<int*>(slots + 2560) + lane;  // SLOTS: the record slot of the record waiting in the lane's slot
+  auto fetch = [&](int at, int rs) {
+    if constexpr (SLOTS) fetch_record_to_lds(in0, in1, in2, at, s_base), *slot_rs = rs;
+    else nx = path_load(in, qbase + at), nx_rs = rs;
   };
   // lane state
   f3 o = mk(0.f, 0.f, 0.f), d = o, c = o;
-  int slot = 0, depth = 1, mark = 0, rpos = 0;
+  int slot = 0, depth = 1, mark = 0, rslot = 0;  // rslot: where the path's retirement record goes (decided when it was taken)
   uint32_t phash = 0u;
   bool valid = false, fresh = false, owes = false;  // owes: the lane's path died and its retirement record is not stored yet
-  while (kc + 1 < b.K && lo >= pre[kc + 1]) ++kc;
   bool has_next = lo + lane < hi;
-  if (has_next) fetch(lo + lane);
+  {
+    int at = 0, rs = 0;
+    assign(has_next, lo + lane, at, rs);
+    if (has_next) fetch(at, rs);
+  }
   int streamed = min(lo + 64, hi);  // records handed to slots so far: [lo, streamed)
-  while (kc + 1 < b.K && streamed >= pre[kc + 1]) ++kc;
   while (true) {
     // ── refill: dead lanes take the record waiting in their slot; the slot gets the next record of the slice ──
     const bool take = !valid && has_next;
@@ -2143,39 +2151,43 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
     if (tm | ballot(owes)) {
       v4f w0, w1;
       float cz;
-      int nslot;
+      int nslot, nrs;
       if constexpr (SLOTS) {
         // everything outstanding here (last refill's transfers, last refill's retirement stores) is a whole iteration old
         asm volatile(
             "s_waitcnt vmcnt(0)\n\t"
-            "ds_read_b128 %0, %4\n\t"
-            "ds_read_b128 %1, %4 offset:1024\n\t"
-            "ds_read_b32 %2, %5\n\t"
-            "ds_read_b32 %3, %5 offset:256\n\t"
+            "ds_read_b128 %0, %5\n\t"
+            "ds_read_b128 %1, %5 offset:1024\n\t"
+            "ds_read_b32 %2, %6\n\t"
+            "ds_read_b32 %3, %6 offset:256\n\t"
+            "ds_read_b32 %4, %6 offset:512\n\t"
             "s_waitcnt lgkmcnt(0)"
-            : "=&v"(w0), "=&v"(w1), "=&v"(cz), "=&v"(nslot)
+            : "=&v"(w0), "=&v"(w1), "=&v"(cz), "=&v"(nslot), "=&v"(nrs)
             : "v"(s16), "v"(s4)
             : "memory");
       } else {
-        w0 = v4f{nx.o.x, nx.o.y, nx.o.z, nx.d.x}, w1 = v4f{nx.d.y, nx.d.z, nx.c.x, nx.c.y}, cz = nx.c.z, nslot = nx.tag.slot;
+        w0 = v4f{nx.o.x, nx.o.y, nx.o.z, nx.d.x}, w1 = v4f{nx.d.y, nx.d.z, nx.c.x, nx.c.y}, cz = nx.c.z, nslot = nx.tag.slot, nrs = nx_rs;
       }
       if (owes) {  // the record of the path that died in this lane (its colour and sample id are still here)
-        const int k = (int)((uint32_t)slot >> b.slot_shift), pl = slot & ((1 << b.slot_shift) - 1);
-        retire_store(rt, true, k, rpos, pl, c);
+#ifndef PT_ABL_NO_RETIRE
+        rt.rec[rslot] = ptd::Word4{c.x, c.y, c.z, __int_as_float(slot & ((1 << b.slot_shift) - 1))};
+#endif
         owes = false;
       }
+      const int rank = rank_in(tm);
+      const bool more = take && streamed + rank < hi;
+      int at = 0, rs = 0;
+      assign(more, streamed + rank, at, rs);
       if (take) {
         o = mk(w0.x, w0.y, w0.z), d = mk(w0.w, w1.x, w1.y), c = mk(w1.z, w1.w, cz);
-        slot = nslot;
+        slot = nslot, rslot = nrs;
         phash = utilhash((uint32_t)global_pixel(b, nslot & ((1 << b.slot_shift) - 1)));
         depth = 1;
         valid = fresh = true;
-        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0));
-        has_next = streamed + rank < hi;
-        if (has_next) fetch(streamed + rank);
+        has_next = more;
+        if (more) fetch(at, rs);
       }
       streamed = min(streamed + (int)__popcll(tm), hi);
-      while (kc + 1 < b.K && streamed >= pre[kc + 1]) ++kc;
     }
     if (!ballot(valid)) break;  // every path of the slice has retired
     bool ready;
@@ -2230,13 +2242,12 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
         bo = shade_decide(mats, b.trace_depth, depth, ih ^ phash, ht, hmat, s);
       }
       const bool alive = ready && s.alive, dead = ready && !s.alive;
-      const int rp = dead ? atomicAdd(&fill[k], 1) : 0;  // lanes of one iteration get consecutive records
       if (dead) atomicAdd(&died[depth & 63], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
       if (alive) shade_bounce(bo, hn, hp, s);
       if (ready) {
         c = s.c;
         if (alive) o = s.o, d = s.d, depth += 1, fresh = true;
-        else valid = false, owes = true, rpos = rp;
+        else valid = false, owes = true;
       }
     }
   }
@@ -2299,7 +2310,8 @@ PT_DEV void collect_load(const ptd::Word4* rec, int n, int i0, CollectChunk& c) 
     c.v[u] = rec[i < n ? i : (n > 0 ? n - 1 : 0)];
   }
 }
-PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int Q, float inv_q, int first, float* tile) {
+// (g0, g1: slots of the region that hold no record — the unused tail of the sub-region with the tile's partial last chunk)
+PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int g0, int g1, int Q, float inv_q, int first, float* tile) {
 #pragma unroll
   for (int u = 0; u < kCollectPPT; ++u) {
     const int i = i0 + u * kCollectThreads + (int)threadIdx.x;
@@ -2307,7 +2319,7 @@ PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int Q, float i
     int jj, qq;
     divmod(pl >> 6, Q, inv_q, jj, qq);
     const int li = jj * 64 + (pl & 63) - first;
-    if (i < n && li >= 0 && li < kCollectPixels) tile[3 * li] = c.v[u].x, tile[3 * li + 1] = c.v[u].y, tile[3 * li + 2] = c.v[u].z;
+    if (i < n && !(i >= g0 && i < g1) && li >= 0 && li < kCollectPixels) tile[3 * li] = c.v[u].x, tile[3 * li + 1] = c.v[u].y, tile[3 * li + 2] = c.v[u].z;
   }
 }
 __global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Queues qs, ptd::RetireBuf ret, float* __restrict__ image) {
@@ -2317,7 +2329,18 @@ __global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Q
   const QueueShare sh = queue_share(b, qs, q);
   const float inv_q = 1.0f / (float)qs.Q;
   const ptd::Word4* rec = ret.rec + (int64_t)q * ret.kmax * ret.seg_cap;  // region (q, 0)
-  const int n = sh.my_pixels;                                              // records per region
+  // Records per region: flat form — my_pixels, appended from the front; otherwise one slot per pixel of the queue's my_nq chunks,
+  // every one filled except the last (64 - N % 64) slots of the sub-region that holds the tile's partial last chunk.
+  int n = sh.my_pixels, g0 = 0, g1 = 0;
+  if (!b.flat) {
+    n = sh.my_nq * 64;
+    const int missing = n - sh.my_pixels;
+    if (missing > 0) {
+      const int quo = sh.my_nq / ret.wq0, rem = sh.my_nq % ret.wq0, rho = (sh.my_nq - 1) % ret.wq0;
+      g1 = (sub_offset(quo, rem, rho) + sub_chunks(quo, rem, rho)) * 64;
+      g0 = g1 - missing;
+    }
+  }
   for (int first = 0; first < sh.my_nq * 64; first += kCollectPixels) {  // one pass per kCollectPixels of the queue's pixels
     float acc[kCollectPPT][3];
     // thread t owns the queue pixels first + t + kCollectThreads * m: chunk jj = index >> 6 is tile chunk q + jj * Q
@@ -2333,10 +2356,10 @@ __global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Q
     CollectChunk c;
     collect_load(rec, n, 0, c);
     for (int k = 0; k < b.K; ++k) {
-      collect_scatter(c, n, 0, qs.Q, inv_q, first, tile);
+      collect_scatter(c, n, 0, g0, g1, qs.Q, inv_q, first, tile);
       for (int i0 = kCollectPixels; i0 < n; i0 += kCollectPixels) {  // regions longer than one chunk (several passes only)
         collect_load(rec + (int64_t)k * ret.seg_cap, n, i0, c);
-        collect_scatter(c, n, i0, qs.Q, inv_q, first, tile);
+        collect_scatter(c, n, i0, g0, g1, qs.Q, inv_q, first, tile);
       }
       if (k + 1 < b.K) collect_load(rec + (int64_t)(k + 1) * ret.seg_cap, n, 0, c);
       __syncthreads();
@@ -2431,7 +2454,7 @@ bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_tab
 // k_paths' search form: 2 = uniform grid walk, 0 = scene tables in LDS (every leaf a top entry), 1 = top list + subtree scans
 int paths_mode(const SceneTables& sc) { return sc.use_grid ? 2 : (tables_in_lds(sc) ? 0 : 1); }
 int paths_lds_bytes(const SceneTables& sc, int mode) {
-  const int rows = iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 1), common = paths_fill_bytes(sc) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + rows;
+  const int rows = iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 1), common = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + rows;
   const int top = sc.num_top * (int)sizeof(ptd::TopEntry);
   switch (mode) {
     case 0: return common + top + sc.num_geoms * (int)sizeof(ptd::Geom) + kWavesPerBlock * paths_wave_bytes<0>() + kMaxTop * 4 + 64 * 4;
