@@ -1996,8 +1996,8 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
 #ifndef PT_PATHS_SCAN_WAVES
 #define PT_PATHS_SCAN_WAVES 5
 #endif
-#ifndef PT_PATHS_GRID_WAVES  // measured in-box, 1000 random objects / C5, Msamples/s at 4 | 5 waves: fast 4549 / 3699 | 3686 / 2817 (the fast build's
-#define PT_PATHS_GRID_WAVES (PT_ARITH == 2 ? 4 : 5)  // 40 B / lane of scratch land in its walk loop), exact 3995 / 3251 | 4316 / 3441
+#ifndef PT_PATHS_GRID_WAVES  // 95-96 VGPRs without scratch since the wave index is scalar; in-box 4 and 5 are level for the fast build, 5 wins for exact
+#define PT_PATHS_GRID_WAVES 5
 #endif
 template <int MODE>
 constexpr bool paths_slots_in_lds() { return MODE != 2; }
