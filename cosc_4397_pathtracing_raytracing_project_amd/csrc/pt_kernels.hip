@@ -1907,26 +1907,28 @@ PT_DEV void fetch_record_to_lds(const void* b0, const void* b1, const void* b2, 
       : [base] "s"(lds_base), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [o16] "v"(off16), [o8] "v"(off8)
       : "memory", "scc");
 }
-// Per-wave LDS of k_paths: closest-hit keys, winner records, the candidate ring (32-bit entries: leaf | geom << 8 | owner lane
-// << 16 — the geom index rides along, so a chunk does not go through nodes[leaf]) and the running totals.  The rays are NOT
-// kept in LDS: the lanes are persistent, a chunk fetches a candidate's ray from its owner's registers (ds_bpermute).
+// Per-wave LDS of k_paths: closest-hit keys, winner records, the candidate ring (16-bit entries: top entry << 6 | owner lane;
+// the chunk looks leaf and geom index up in tword[top entry] = leaf | geom << 8, so it does not go through nodes[leaf]) and the
+// running totals.  The rays are NOT kept in LDS: the lanes are persistent, a chunk fetches a candidate's ray from its owner's
+// registers (ds_bpermute).
 struct Lanes {
   unsigned long long* best;  // [64]
   float* rec;                // [6][64]  normal xyz, point xyz
-  uint32_t* ent;             // [kRing]
+  uint16_t* ent;             // [kRing]
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
 };
-constexpr int kLanesBytes = 64 * 8 + 6 * 64 * 4 + kRing * 4;
+constexpr int kLanesBytes = 64 * 8 + 6 * 64 * 4 + kRing * 2;
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all 64 lanes active.
-PT_DEV void paths_chunk(Lanes& c, int n, int lane, f3 o, f3 d, const ptd::Geom* __restrict__ geoms) {
+PT_DEV void paths_chunk(Lanes& c, int n, int lane, f3 o, f3 d, const uint32_t* tword, const ptd::Geom* __restrict__ geoms) {
   const bool valid = lane < n;
   const uint32_t entry = c.ent[(c.head + lane) & (kRing - 1)];
-  const int src = (int)(entry >> 16) & 63;
-  const uint32_t leaf = entry & 255u;
+  const int src = (int)(entry & 63u);
+  const uint32_t tw = tword[valid ? entry >> 6 : 0u];
+  const uint32_t leaf = tw & 255u;
   const f3 ro = mk(bperm(src, o.x), bperm(src, o.y), bperm(src, o.z));
   const f3 rd = mk(bperm(src, d.x), bperm(src, d.y), bperm(src, d.z));
-  const ptd::Geom* G = geoms + (valid ? (int)((entry >> 8) & 255u) : 0);
+  const ptd::Geom* G = geoms + (valid ? (int)(tw >> 8) : 0);
   f3 pt = mk(0.f, 0.f, 0.f), nrm = mk(0.f, 0.f, 0.f);
   const float t = geom_test<-1, false>(G, ro, rd, pt, nrm, mk(0.f, 0.f, 0.f));
   const uint32_t tb = __float_as_uint(t);
@@ -1946,7 +1948,7 @@ PT_DEV void paths_chunk(Lanes& c, int n, int lane, f3 o, f3 d, const ptd::Geom* 
 }
 // Candidate search of the fresh lanes of a persistent group (LDS-table scenes: every top entry is a leaf) — carry_search's
 // two-phase form with the per-lane resolution mark: `mark` = ring entries appended up to and including the lane's last one.
-// tword[e] = leaf | geom << 8 of top entry e.
+// tword[e] = leaf | geom << 8 of top entry e (read by the chunks).
 PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int ntop, const ptd::Geom* __restrict__ geoms, f3 o, f3 d,
                          bool fresh, int lane, int& mark) {
   const RayInv ri = ray_inv(d, o);
@@ -1967,21 +1969,20 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
     }
   }
   mask = fresh ? mask : 0u;
-  const uint32_t tag = (uint32_t)lane << 16;
   while (true) {
     const unsigned long long m = ballot(mask != 0u);
     if (!m) break;
-    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    const int rank = rank_in(m);
     if (mask != 0u) {
       const int te = ntop - 1 - __builtin_ctz(mask);
       mask &= mask - 1u;
-      c.ent[(c.head + c.count + rank) & (kRing - 1)] = tword[te] | tag;
+      c.ent[(c.head + c.count + rank) & (kRing - 1)] = (uint16_t)((te << 6) | lane);
       if (mask == 0u) mark = c.appended + rank + 1;
     }
     const int cnt = __popcll(m);
     c.count += cnt;
     c.appended += cnt;
-    if (c.count >= 64) paths_chunk(c, 64, lane, o, d, geoms);
+    if (c.count >= 64) paths_chunk(c, 64, lane, o, d, tword, geoms);
   }
 }
 // MODE 0: scene tables in LDS, every leaf a top entry (cornell.txt: the form described above).
@@ -2002,7 +2003,7 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
 template <int MODE>
 constexpr bool paths_slots_in_lds() { return MODE != 2; }
 template <int MODE>
-constexpr int paths_extra_bytes() { return (paths_slots_in_lds<MODE>() ? kSlotBytes : 0) + 256; }  // refill slots + 64 counters: paths retired per depth
+constexpr int paths_extra_bytes() { return (paths_slots_in_lds<MODE>() ? kSlotBytes : 0) + 512; }  // refill slots + 64 counters: paths retired per depth + 64: record slots per sub-list
 template <int MODE>
 constexpr int paths_wave_bytes() {
   return (MODE == 0 ? kLanesBytes : MODE == 1 ? carry_bytes<false, 1>() : grid_wave_bytes<false>()) + paths_extra_bytes<MODE>();
@@ -2045,7 +2046,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   Lanes cy;  // MODE 0
   cy.best = reinterpret_cast<unsigned long long*>(wbase);
   cy.rec = reinterpret_cast<float*>(wbase + 64 * 8);
-  cy.ent = reinterpret_cast<uint32_t*>(wbase + 64 * 8 + 6 * 64 * 4);
+  cy.ent = reinterpret_cast<uint16_t*>(wbase + 64 * 8 + 6 * 64 * 4);
   cy.head = cy.count = cy.appended = cy.processed = 0;
   Carry<false, 1> cb = carry_init<false, 1>(wbase);  // MODES 1, 2 (the same bytes)
   CellRing cr{reinterpret_cast<uint32_t*>(wbase + carry_bytes<false, 1>()), 0, 0, nullptr};
@@ -2054,6 +2055,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   constexpr bool SLOTS = paths_slots_in_lds<MODE>();
   char* slots = wbase + core_bytes;  // SLOTS: [64] x 16 B, [64] x 16 B, [64] x 4 B, [64] x 4 B
   int* died = reinterpret_cast<int*>(slots + (SLOTS ? kSlotBytes : 0));  // [64]: paths of this wave retired AT depth d (statistics; PT_MAX_DEPTH = 64)
+  int* fillc = died + 64;                                                 // [64]: next record slot per sub-list the wave's slice touches
   const int ntop = sc.num_top;
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wib);  // (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
   const int lane = lane_id();
@@ -2079,35 +2081,49 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const int lo = min(r * per, total), hi = min(lo + per, total);
   if (r == 0 && lane == 0) cnt[per_depth * 1 + (size_t)q * qs.cnt_stride] = total;  // statistics: rays traced at depth 1
   int ce = ne, ck = 0, crho = 0, cstart = total, ccnt = 0, clist = 0, crec = 0;  // cursor (wave-uniform): sub-list e = ck * wq0 + crho; an empty slice leaves it at the end
-  auto cursor_bases = [&]() {
+  int cord = 0;          // how many sub-lists the cursor has been in before this one
+  bool append = true;    // wave-uniform, see below
+  auto cursor_bases = [&](int first_rank) {
     const int sub0 = ck * rt.seg_cap + sub_offset(quo, rem, crho) * 64;
     clist = sub0;
     crec = sub0 + __builtin_amdgcn_readfirstlane((int)(uint32_t)(rt.sub[min(ce, ne - 1)] >> 32));
+    if (lane == 0) fillc[cord & 63] = crec + (first_rank - cstart);  // where this wave's first record of the sub-list goes
   };
   if (lo < hi) {
-    int cum = 0;
-    for (int e0 = 0; e0 < ne; e0 += 64) {
+    // the sub-list rank lo lies in; and how many sub-lists the slice touches.  The records of the slice's paths out of ONE
+    // sub-list fill a contiguous range of its sub-region, whatever order they arrive in, so a wave appends them in order of
+    // retirement through a counter per sub-list in LDS (fillc: lanes of one sub-list that die together get consecutive slots,
+    // as the per-iteration counters of the earlier layouts gave) — while the slice touches at most 64 of them; beyond that
+    // (tiles of a few pixels per wave) a path's record goes to the slot its own list index names.
+    int cum = 0, nsub = 0;
+    bool found = false;
+    for (int e0 = 0; e0 < ne && cum < hi; e0 += 64) {
       const int n = count_of(e0 + lane);
       int sum;
       const int before = wave_prefix6(n, sum);
-      const unsigned long long here = ballot(n > 0 && cum + before <= lo && lo < cum + before + n);
-      if (here) {
-        const int l = __builtin_ctzll(here);
-        ce = e0 + l, cstart = cum + __builtin_amdgcn_readlane(before, l), ccnt = __builtin_amdgcn_readlane(n, l);
-        ck = ce / wq0, crho = ce - ck * wq0;
-        break;
+      if (!found) {
+        const unsigned long long here = ballot(n > 0 && cum + before <= lo && lo < cum + before + n);
+        if (here) {
+          const int l = __builtin_ctzll(here);
+          ce = e0 + l, cstart = cum + __builtin_amdgcn_readlane(before, l), ccnt = __builtin_amdgcn_readlane(n, l);
+          ck = ce / wq0, crho = ce - ck * wq0;
+          found = true;
+        }
       }
+      nsub += (int)__popcll(ballot(n > 0 && cum + before < hi && cum + before + n > lo));
       cum += sum;
     }
-    cursor_bases();
+    append = nsub <= 64;
+    cursor_bases(lo);
   }
-  // Path index (inside the queue's region) and record slot (inside the queue's regions) of the rays of global rank `rank`, for
-  // the lanes that `want` one; ranks only grow, so the cursor only moves forward.  Wave-uniform control flow.
+  // Path index (inside the queue's region) of the rays of global rank `rank`, for the lanes that `want` one, and what locates
+  // their retirement records: the sub-list's counter (append) or the record slot itself.  Ranks only grow, so the cursor only
+  // moves forward.  Wave-uniform control flow.
   auto assign = [&](bool want, int rank, int& at, int& rs) {
     bool pending = want;
     while (true) {
       const bool in = pending && rank < cstart + ccnt;
-      if (in) at = clist + (rank - cstart), rs = crec + (rank - cstart);
+      if (in) at = clist + (rank - cstart), rs = append ? (cord & 63) : crec + (rank - cstart);
       pending = pending && !in;
       if (!ballot(pending) || ce >= ne) break;
       cstart += ccnt;  // on to the next sub-list that holds anything
@@ -2116,7 +2132,8 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
         if (++crho == wq0) crho = 0, ++ck;
         ccnt = __builtin_amdgcn_readfirstlane(count_of(ce));
       } while (ce < ne && ccnt == 0);
-      cursor_bases();
+      ++cord;
+      cursor_bases(cstart);
     }
   };
   const uint32_t s_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(slots));
@@ -2134,7 +2151,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   };
   // lane state
   f3 o = mk(0.f, 0.f, 0.f), d = o, c = o;
-  int slot = 0, depth = 1, mark = 0, rslot = 0;  // rslot: where the path's retirement record goes (decided when it was taken)
+  int slot = 0, depth = 1, mark = 0, rslot = 0;  // rslot: the path's sub-list counter (append) / record slot, from when it was taken; at death: the record slot
   uint32_t phash = 0u;
   bool valid = false, fresh = false, owes = false;  // owes: the lane's path died and its retirement record is not stored yet
   bool has_next = lo + lane < hi;
@@ -2197,7 +2214,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       // ── which lanes are resolved?  Too few, with candidates pending: run them as a partial chunk ──
       ready = valid && (cy.processed - mark) >= 0;
       if (cy.count > 0 && __popcll(ballot(ready)) < kPathsMinReady) {
-        paths_chunk(cy, cy.count, lane, o, d, geoms);  // count < 64 here
+        paths_chunk(cy, cy.count, lane, o, d, tword, geoms);  // count < 64 here
         ready = valid;
       }
     } else {
@@ -2243,6 +2260,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       }
       const bool alive = ready && s.alive, dead = ready && !s.alive;
       if (dead) atomicAdd(&died[depth & 63], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
+      if (dead && append) rslot = atomicAdd(&fillc[rslot], 1);  // lanes of one sub-list get consecutive record slots
       if (alive) shade_bounce(bo, hn, hp, s);
       if (ready) {
         c = s.c;
@@ -2483,8 +2501,15 @@ int lds_table_limit(const SceneTables& sc, int forced_bytes) {
   return (with >= without && with > 0) ? tbl : -1;
 }
 
+// The occupancy query over-reports by one workgroup when the LDS of a block is a few hundred bytes under a 1/n share of the
+// CU's 160 KB (measured, round 4: 27,088 B per block: 6 reported, 5 resident — and a persistent grid one block too large runs
+// that block's whole share after everybody else: k_paths 1335 -> 1607 us).  A share is therefore counted in 1280-byte granules.
+#ifndef PT_LDS_GRANULE
+#define PT_LDS_GRANULE 1280
+#endif
+int lds_share_limit(int bytes) { return bytes > 0 ? (160 * 1024) / (((bytes + PT_LDS_GRANULE - 1) / PT_LDS_GRANULE) * PT_LDS_GRANULE) : 8; }
 int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
-  int n = 0;
+  int n = 0, lds = 0;
   hipError_t e = hipSuccess;
   const int tbl = table_bytes(sc);
   const bool in_lds = tables_in_lds(sc);
@@ -2503,20 +2528,22 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false, false>, kBlock, 0);
       break;
     case kPrimary:
-      if (sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false, true>, kBlock, primary_grid_lds_bytes(sc));
-      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, fused_lds_bytes(sc, false, kWaveLds, true));
+      if (sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false, true>, kBlock, lds = primary_grid_lds_bytes(sc));
+      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, lds = fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true));
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, lds = fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kPaths:
-      if (paths_mode(sc) == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<0>, kBlock, paths_lds_bytes(sc, 0));
-      else if (paths_mode(sc) == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<1>, kBlock, paths_lds_bytes(sc, 1));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<2>, kBlock, paths_lds_bytes(sc, 2));
+      lds = paths_lds_bytes(sc, paths_mode(sc));
+      if (paths_mode(sc) == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<0>, kBlock, lds);
+      else if (paths_mode(sc) == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<1>, kBlock, lds);
+      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<2>, kBlock, lds);
       break;
     case kShade:
       e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
       break;
   }
   if (e != hipSuccess || n < 1) n = 1;
+  n = min(n, max(1, lds_share_limit(lds)));
   return n > 8 ? 8 : n;
 }
 
