@@ -1356,6 +1356,8 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
     return;
   }
   uint32_t pend = 0;  // per lane: top entries that are subtrees and whose box this ray passes
+  PT_STAT(0, 1);
+  PT_STAT(13, __popcll(ballot(valid)));
   float4 A = top[0], B = top[1];
   for (int e = 0; e < ntop; ++e) {
     const float4 TA = A, TB = B;  // bmin.xyz, bmax.x | bmax.yz, idx, link
@@ -1363,6 +1365,7 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
     const int t_idx = __builtin_amdgcn_readfirstlane(__float_as_int(TB.z));
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
     const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
+    PT_STAT(8, __popcll(ballot(pass)));
     if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, lane, nodes, geoms);
     else if (pass) pend |= 1u << e;
   }
@@ -1383,8 +1386,13 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
       const bool idle = wk.cur >= wk.end;
       const unsigned long long I = ballot(idle);
       if (I == ~0ull) break;
-      if (__popcll(I) >= kStealMin) steal_step(wk, pend, xm, idle, I, c.slot, top, lane);
+      if (__popcll(I) >= kStealMin) {
+        PT_STAT(3, 1);
+        steal_step(wk, pend, xm, idle, I, c.slot, top, lane);
+      }
       const bool act = wk.cur < wk.end;
+      PT_STAT(1, 1);
+      PT_STAT(2, __popcll(ballot(act)));
       const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + wk.own) + 1]) + cull;
       bool cand;
       int at_n, aux;
@@ -2221,7 +2229,11 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       // ── search of every live lane (all of them have a new ray), then all its candidates ──
       cb.best[lane] = kNoHit;
       if constexpr (MODE == 2) grid_search<1>(cb, cr, sc, nodes, geoms, o, d, valid, lane, 0);
-      else carry_search<true, 1>(cb, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
+      else {
+        PT_STAT(14, 1);
+        PT_STAT(15, __popcll(ballot(valid)));
+        carry_search<true, 1>(cb, top, ntop, nodes, geoms, o, d, valid, lane, 0, sc.cull_margin, sc.top_xor);
+      }
       while (cb.count > 0) carry_chunk<false, 1, false, MODE == 2>(cb, min(64, cb.count), lane, nodes, geoms);
       ready = valid;
     }
