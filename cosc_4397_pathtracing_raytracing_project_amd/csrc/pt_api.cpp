@@ -33,7 +33,7 @@ constexpr bool kAblateBuild = false;  // release library: pt_init rejects them
 #endif
 
 std::string g_err;
-constexpr int kGridNodes = 1024;       // scenes from this many BVH nodes on are candidates for the uniform grid (build_grid, choose_traversal)
+constexpr int kGridNodes = 600;        // scenes from this many BVH nodes on are candidates for the uniform grid (build_grid, choose_traversal); the ladder scene of 500 primitives (999 nodes): scan 3.9 k, grid 4.7 k Msamples/s, 156 primitives (311 nodes): 5.5 / 5.3
 constexpr int kTightNodes = 64;        // scenes from this many BVH nodes on test sphere leaves against the ellipsoid's box (sphere_tight_box); the
                                        // reference's own scenes (cornell.txt: 13 nodes) keep the reference's boxes
 }  // namespace
@@ -219,7 +219,10 @@ void build_top(const std::vector<PtBVHNode>& ref, const std::vector<ptd::Node>& 
   };
   std::vector<Cut> cut{{0, 0u, 0}};
   auto span = [&](int ref_idx) { return thr[where[ref_idx]].skip - where[ref_idx]; };
-  while ((int)cut.size() < ptk::kMaxTop) {
+  const char* te = getenv("PT_TOP_ENTRIES");  // experiment knob: a smaller cut (scenes with subtrees only: the LDS-table kernels need every leaf in the list)
+  const int want = te ? std::max(1, std::min(atoi(te), ptk::kMaxTop)) : ptk::kMaxTop;
+  const int max_top = ((int)(ref.size() + 1) / 2 <= ptk::kMaxTop && !getenv("PT_LDS_TABLE_KB")) ? ptk::kMaxTop : want;
+  while ((int)cut.size() < max_top) {
     int best = -1;
     for (size_t i = 0; i < cut.size(); ++i)
       if (ref[cut[i].ref_idx].left >= 0 && cut[i].len < 24 && (best < 0 || span(cut[i].ref_idx) > span(cut[best].ref_idx)))
@@ -530,6 +533,10 @@ ptk::SceneTables tables(const Ctx& g) {
   t.max_batch_iters = g.K;
   t.has_triangles = g.has_triangles ? 1 : 0;
   t.trace_depth = g.depth;
+  {
+    const char* e = getenv("PT_SCAN_NODES_LDS");  // experiment knob: 0 / 1 = never / always; default: when it costs k_paths no resident workgroup
+    t.scan_nodes_lds = e ? (atoi(e) ? 1 : 0) : -1;
+  }
   // debug_flags 256 builds and uses the grid for any scene, 512 never (A/B, same results)
   t.use_grid = g.have_grid && g.grid_enabled && !(g.debug_flags & 512) ? 1 : 0;
   if (t.use_grid) {

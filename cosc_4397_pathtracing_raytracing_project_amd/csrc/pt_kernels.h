@@ -52,6 +52,8 @@ struct SceneTables {
   int32_t use_grid;
   int32_t trace_depth;    // of the context (k_paths sizes its iteration-hash rows with it)
   int32_t has_triangles;  // mesh extension: some geoms are PT_GEOM_TRIANGLE (the sphere-only chunk specialisation is off)
+  int32_t scan_nodes_lds;  // k_paths mode 1: 1 = the threaded nodes are staged in LDS for the subtree scans (scenes of a few hundred nodes:
+                           // 64 primitives +4 % Msamples/s), 0 = read from memory, -1 = staged when that costs no resident workgroup per CU (resolved at launch)
 };
 
 struct BatchInfo {

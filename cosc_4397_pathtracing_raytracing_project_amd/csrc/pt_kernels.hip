@@ -116,7 +116,8 @@ constexpr bool kAblate = false;
 __device__ unsigned long long g_walk_stats[16];
 #define PT_STAT(i, v)                                                             \
   do {                                                                            \
-    if (lane_id() == 0) atomicAdd(&g_walk_stats[i], (unsigned long long)(v));     \
+    const unsigned long long pt_stat_v = (unsigned long long)(v); /* by every lane: v may hold a ballot */ \
+    if (lane_id() == 0) atomicAdd(&g_walk_stats[i], pt_stat_v);                   \
   } while (0)
 PT_DEV int wave_max_stat(int v) {
   for (int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o));
@@ -139,6 +140,7 @@ constexpr int kStealMin = PT_STEAL_MIN;  // idle lanes needed before a work-stea
 #endif
 constexpr int kPrimaryWaves = PT_PRIMARY_WAVES;
 
+typedef float v4f __attribute__((ext_vector_type(4)));
 struct f3 {
   float x, y, z;
 };
@@ -578,12 +580,12 @@ PT_DEV uint32_t octant_mask(const RayInv& ri, unsigned long long top_xor) {
 // One step of a lane's stackless subtree scan.  On return `cur` is advanced, `cand` says whether the node is a
 // leaf whose box the ray passes (and that is not culled), `leaf` is its index in `nodes`, `geom` its geom index.
 // bt: the ray's best hit distance so far + SceneTables::cull_margin (closer-hit cull).
-template <bool EX = false>
-PT_DEV void scan_step(const ptd::Node* __restrict__ nodes, f3 o, const RayInv& ri, bool act, int& cur, float bt,
+template <bool EX = false, typename NP = const v4f*>
+PT_DEV void scan_step(NP nodes4, f3 o, const RayInv& ri, bool act, int& cur, float bt,
                       bool& cand, int& leaf, int& geom) {
   const int at_n = act ? cur : 0;
-  const float4 NA = reinterpret_cast<const float4*>(nodes)[2 * at_n];      // bmin.xyz, bmax.x
-  const float4 NB = reinterpret_cast<const float4*>(nodes)[2 * at_n + 1];  // bmax.yz, skip, geom
+  const v4f NA = nodes4[2 * at_n];      // bmin.xyz, bmax.x
+  const v4f NB = nodes4[2 * at_n + 1];  // bmax.yz, skip, geom
   float tn;
   const bool in = act && Ar<EX>::slab_t(o, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn) && !(tn > bt);
   geom = __float_as_int(NB.w);
@@ -860,7 +862,7 @@ PT_DEV void trace_group(const WaveLds& w, const float4* top, int ntop, const ptd
       const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(w.best)[2 * wk.own + 1]) + cull;
       bool cand;
       int at_n, aux;
-      scan_step<EX>(nodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
+      scan_step<EX>(reinterpret_cast<const v4f*>(nodes), wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
       const bool cbox = cand && geoms[aux].type == 1;
       const bool csph = cand && !cbox;
       const unsigned long long mb = ballot(cbox), msp = ballot(csph);
@@ -1215,6 +1217,8 @@ struct Carry {
   int head, count;           // wave-uniform
   int appended, processed;   // running totals (wave-uniform)
   int debug;                 // BatchInfo::debug
+  const __attribute__((address_space(3))) v4f* lnodes;  // the threaded nodes in LDS (k_paths mode 1 on scenes of a few hundred nodes) when lds_nodes
+  bool lds_nodes;
 };
 template <bool SMALL, int NPAR = 2>
 __host__ __device__ constexpr int carry_bytes() {
@@ -1234,6 +1238,8 @@ PT_DEV Carry<SMALL, NPAR> carry_init(char* base) {
   c.debug = 0;
   c.gix = nullptr;
   c.qo_tab = nullptr;
+  c.lnodes = nullptr;
+  c.lds_nodes = false;
   return c;
 }
 // Primitive tests for the first n (<= 64) pending entries; wave-uniform control flow, all lanes active.
@@ -1396,7 +1402,8 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
       const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + wk.own) + 1]) + cull;
       bool cand;
       int at_n, aux;
-      scan_step(nodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
+      if (c.lds_nodes) scan_step(c.lnodes, wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
+      else scan_step(reinterpret_cast<const v4f*>(nodes), wk.o, wk.ri, act, wk.cur, bt, cand, at_n, aux);
       carry_append(c, cand, (uint32_t)at_n, par, wk.own, lane, nodes, geoms);
     }
   }
@@ -1880,7 +1887,6 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
 #endif
 constexpr int kPathsWaves = PT_PATHS_WAVES, kPathsMinReady = PT_PATHS_MIN_READY;
 constexpr int kSlotBytes = 64 * 16 + 64 * 16 + 64 * 4 + 64 * 4 + 64 * 4;  // planes 0, 1 (16 B per lane), colour.z, sample id, record slot
-typedef float v4f __attribute__((ext_vector_type(4)));
 PT_DEV uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 // memory -> LDS without passing through VGPRs: path record i of a queue (b0 / b1 / b2 = the queue's first record in planes 0,
 // 1, 2; wave-uniform, so they are scalar bases and a lane supplies 32-bit byte offsets only) of every active lane to lds_base
@@ -1957,7 +1963,12 @@ PT_DEV void paths_chunk(Lanes& c, int n, int lane, f3 o, f3 d, const uint32_t* t
 // Candidate search of the fresh lanes of a persistent group (LDS-table scenes: every top entry is a leaf) — carry_search's
 // two-phase form with the per-lane resolution mark: `mark` = ring entries appended up to and including the lane's last one.
 // tword[e] = leaf | geom << 8 of top entry e (read by the chunks).
-PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int ntop, const ptd::Geom* __restrict__ geoms, f3 o, f3 d,
+#ifndef PT_TOP_SCALAR
+#define PT_TOP_SCALAR 1  // mode 0: the top list's boxes come through scalar loads (constant address space: s_load_dwordx8 into SGPRs, the scalar cache) instead of broadcast LDS reads into VGPRs
+#endif
+typedef __attribute__((address_space(4))) const v4f cfloat4;  // wave-uniform indices into it become scalar loads (a builtin vector: HIP's float4 class cannot be copied out of another address space)
+template <typename TOP>
+PT_DEV void paths_search(Lanes& c, TOP* top, const uint32_t* tword, int ntop, const ptd::Geom* __restrict__ geoms, f3 o, f3 d,
                          bool fresh, int lane, int& mark) {
   const RayInv ri = ray_inv(d, o);
   if (fresh) {
@@ -1966,13 +1977,15 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
   }
   // box tests, eight at a time fully unrolled (no loop-carried box registers to rotate); bit (ntop - 1 - e) of the mask = entry e
   uint32_t mask = 0;
-  for (int e0 = 0; e0 < ntop; e0 += 8) {
+  {
+    for (int e0 = 0; e0 < ntop; e0 += 8) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u;
-      if (e < ntop) {
-        const float4 A = top[2 * e], B = top[2 * e + 1];
-        mask = push_bit(mask, slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y));
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u;
+        if (e < ntop) {
+          const auto A = top[2 * e], B = top[2 * e + 1];
+          mask = push_bit(mask, slab(o, ri, A.x, A.y, A.z, A.w, B.x, B.y));
+        }
       }
     }
   }
@@ -2008,8 +2021,11 @@ PT_DEV void paths_search(Lanes& c, const float4* top, const uint32_t* tword, int
 #ifndef PT_PATHS_GRID_WAVES  // 95-96 VGPRs without scratch since the wave index is scalar; in-box 4 and 5 are level for the fast build, 5 wins for exact
 #define PT_PATHS_GRID_WAVES 5
 #endif
+#ifndef PT_SLOTS_MODES
+#define PT_SLOTS_MODES 0  // experiment: 0 = only mode 0 keeps refill slots in LDS
+#endif
 template <int MODE>
-constexpr bool paths_slots_in_lds() { return MODE != 2; }
+constexpr bool paths_slots_in_lds() { return MODE == 0 || (MODE == 1 && PT_SLOTS_MODES == 1); }
 template <int MODE>
 constexpr int paths_extra_bytes() { return (paths_slots_in_lds<MODE>() ? kSlotBytes : 0) + 512; }  // refill slots + 64 counters: paths retired per depth + 64: record slots per sub-list
 template <int MODE>
@@ -2036,6 +2052,13 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
     geoms = reinterpret_cast<const ptd::Geom*>(lds + tbl);
     tbl += nb_geoms;
   }
+  const char* lnodes = nullptr;
+  if (MODE == 1 && sc.scan_nodes_lds > 0) {
+    const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
+    stage16(lds + tbl, sc.nodes, nb_nodes);
+    lnodes = lds + tbl;
+    tbl += nb_nodes;
+  }
   constexpr int wave_bytes = paths_wave_bytes<MODE>();
   constexpr int core_bytes = wave_bytes - paths_extra_bytes<MODE>();
   const int he = iter_hash_entries(sc);
@@ -2060,6 +2083,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   CellRing cr{reinterpret_cast<uint32_t*>(wbase + carry_bytes<false, 1>()), 0, 0, nullptr};
   if (MODE == 2) cb.gix = cr.ent + kCellRing, cr.rinv = reinterpret_cast<float*>(cr.ent + kCellRing + kRing);
   cb.debug = b.debug;
+  cb.lnodes = (const __attribute__((address_space(3))) v4f*)(lnodes ? lnodes : lds), cb.lds_nodes = lnodes != nullptr;
   constexpr bool SLOTS = paths_slots_in_lds<MODE>();
   char* slots = wbase + core_bytes;  // SLOTS: [64] x 16 B, [64] x 16 B, [64] x 4 B, [64] x 4 B
   int* died = reinterpret_cast<int*>(slots + (SLOTS ? kSlotBytes : 0));  // [64]: paths of this wave retired AT depth d (statistics; PT_MAX_DEPTH = 64)
@@ -2218,7 +2242,10 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
     bool ready;
     if constexpr (MODE == 0) {
       // ── search: box tests + appends for the lanes with a new ray; full chunks as the ring fills ──
-      if (ballot(fresh)) paths_search(cy, top, tword, ntop, geoms, o, d, fresh, lane, mark);
+      if (ballot(fresh)) {
+        if constexpr (PT_TOP_SCALAR != 0) paths_search(cy, (cfloat4*)(uintptr_t)sc.top, tword, ntop, geoms, o, d, fresh, lane, mark);
+        else paths_search(cy, top, tword, ntop, geoms, o, d, fresh, lane, mark);
+      }
       // ── which lanes are resolved?  Too few, with candidates pending: run them as a partial chunk ──
       ready = valid && (cy.processed - mark) >= 0;
       if (cy.count > 0 && __popcll(ballot(ready)) < kPathsMinReady) {
@@ -2483,12 +2510,24 @@ int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::
 bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
 // k_paths' search form: 2 = uniform grid walk, 0 = scene tables in LDS (every leaf a top entry), 1 = top list + subtree scans
 int paths_mode(const SceneTables& sc) { return sc.use_grid ? 2 : (tables_in_lds(sc) ? 0 : 1); }
+int lds_share_limit(int bytes);
+int paths_lds_bytes(const SceneTables& sc, int mode);
+// SceneTables::scan_nodes_lds == -1 resolved: the nodes go to LDS when the scan form's workgroups per CU (LDS share) stay the same
+SceneTables resolve_scan_nodes(const SceneTables& sc) {
+  SceneTables t = sc;
+  if (t.scan_nodes_lds >= 0) return t;
+  SceneTables with = sc, without = sc;
+  with.scan_nodes_lds = 1, without.scan_nodes_lds = 0;
+  const int bw = paths_lds_bytes(with, 1), bo = paths_lds_bytes(without, 1);
+  t.scan_nodes_lds = (bw <= 64 * 1024 && lds_share_limit(bw) >= min(lds_share_limit(bo), PT_PATHS_SCAN_WAVES)) ? 1 : 0;  // (registers allow PT_PATHS_SCAN_WAVES workgroups per CU)
+  return t;
+}
 int paths_lds_bytes(const SceneTables& sc, int mode) {
   const int rows = iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 1), common = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + rows;
   const int top = sc.num_top * (int)sizeof(ptd::TopEntry);
   switch (mode) {
     case 0: return common + top + sc.num_geoms * (int)sizeof(ptd::Geom) + kWavesPerBlock * paths_wave_bytes<0>() + kMaxTop * 4 + 64 * 4;
-    case 1: return common + top + kWavesPerBlock * paths_wave_bytes<1>();
+    case 1: return common + top + kWavesPerBlock * paths_wave_bytes<1>() + (sc.scan_nodes_lds > 0 ? sc.num_nodes * (int)sizeof(ptd::Node) : 0);
     default: return common + kWavesPerBlock * paths_wave_bytes<2>();
   }
 }
@@ -2545,7 +2584,7 @@ int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, lds = fused_lds_bytes(sc, false, kWaveLds, true));
       break;
     case kPaths:
-      lds = paths_lds_bytes(sc, paths_mode(sc));
+      lds = paths_lds_bytes(resolve_scan_nodes(sc), paths_mode(sc));
       if (paths_mode(sc) == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<0>, kBlock, lds);
       else if (paths_mode(sc) == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<1>, kBlock, lds);
       else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<2>, kBlock, lds);
@@ -2590,7 +2629,8 @@ void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::C
   else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
 }
 
-void launch_paths(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret) {
+void launch_paths(hipStream_t s, int grid, const SceneTables& sc_in, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret) {
+  const SceneTables sc = resolve_scan_nodes(sc_in);
   const int bytes = paths_lds_bytes(sc, paths_mode(sc));
   if (paths_mode(sc) == 0) hipLaunchKernelGGL(k_paths<0>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
   else if (paths_mode(sc) == 1) hipLaunchKernelGGL(k_paths<1>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
