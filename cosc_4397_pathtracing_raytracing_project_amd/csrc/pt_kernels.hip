@@ -1964,7 +1964,8 @@ PT_DEV void paths_chunk(Lanes& c, int n, int lane, f3 o, f3 d, const uint32_t* t
 // two-phase form with the per-lane resolution mark: `mark` = ring entries appended up to and including the lane's last one.
 // tword[e] = leaf | geom << 8 of top entry e (read by the chunks).
 #ifndef PT_TOP_SCALAR
-#define PT_TOP_SCALAR 1  // mode 0: the top list's boxes come through scalar loads (constant address space: s_load_dwordx8 into SGPRs, the scalar cache) instead of broadcast LDS reads into VGPRs
+#define PT_TOP_SCALAR (PT_ARITH == 2)  // mode 0, fast build: the top list's boxes come through scalar loads (constant address space: s_load into SGPRs, the scalar cache) instead of
+                                       // broadcast LDS reads into VGPRs: 73 -> 67 VGPRs; in-box fast +0.8 %, exact -1.4 % (its longer tests already cover the LDS latency)
 #endif
 typedef __attribute__((address_space(4))) const v4f cfloat4;  // wave-uniform indices into it become scalar loads (a builtin vector: HIP's float4 class cannot be copied out of another address space)
 template <typename TOP>
