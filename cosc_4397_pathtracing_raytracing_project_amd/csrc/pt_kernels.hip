@@ -159,101 +159,7 @@ PT_DEV uint32_t push_bit(uint32_t m, bool bit) {
 PT_DEV int rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0)); }
 PT_DEV f3 mk(float x, float y, float z) { return f3{x, y, z}; }
 
-// Correctly rounded square root / reciprocal / quotient at about 60 % of the price of the compiler's expansions — same
-// results, bit for bit.  The compiler's expansions have to work for every input; three to seven of their 11 (divide) / 16
-// (sqrt) instructions — all of the half-rate kind — only serve inputs a path tracer does not see: v_div_scale / v_div_fmas /
-// v_div_fixup rescale operands whose quotient could leave the normal range and patch up zeros, infinities and NaNs; the
-// sqrt expansion pre-scales inputs below 2^-96, post-scales the result and restores 0 / inf / NaN with a class test.  When
-// EVERY active lane of the wave has operands inside a range where those instructions are the identity (one integer
-// compare per operand and a scalar branch), what remains is executed:
-//   sqrt   s = v_sqrt_f32(x); the neighbours s -/+ 1 ulp; residuals fma(-s', s, x); pick as the expansion does
-//   a / b  r = v_rcp_f32(b), one Newton step on r, q = a r, two residual corrections of q — the expansion's FMA chain, with a
-//          plain FMA where v_div_fmas (which is an FMA unless v_div_scale set VCC) stood
-// otherwise the wave runs the compiler's expansion.  Identity by construction inside the range (it is the same instruction
-// sequence); pt_selfcheck_ieee verifies it on the device against `__builtin_sqrtf`, `1.0f / x` and `a / b` for all 2^32 bit
-// patterns of x and for 2^33 operand pairs (tests/test_gpu_ieee_ops.py).  -DPT_IEEE_FAST=0 builds the plain expansions.
-#ifndef PT_IEEE_FAST
-#define PT_IEEE_FAST 1
-#endif
-namespace ieee {
-constexpr bool kGuarded = PT_IEEE_FAST != 0;
-PT_DEV bool every_lane(bool ok) { return ballot(!ok) == 0ull; }
-// |v| in [2^-47, 2^47): the exponents of numerator and denominator differ by less than 96, so v_div_scale leaves both as they
-// are (VCC = 0, v_div_fmas is a plain FMA) and the quotient is a normal number — by construction, not only by test (round 3's
-// [2^-60, 2^60] relied on the scaled path giving the same result, which the device self-check confirmed but nothing proved)
-PT_DEV bool div_range(float v) { return ((__float_as_uint(v) & 0x7fffffffu) - 0x28000000u) < (0x57000000u - 0x28000000u); }
-// x in [2^-94, 2^60): above the expansion's pre-scaling threshold (2^-96), finite; the root lies in [2^-47, 2^30), inside div_range
-PT_DEV bool sqrt_range(float x) { return (__float_as_uint(x) - 0x10800000u) < (0x5d800000u - 0x10800000u); }
-PT_DEV float sqrt_core(float x) {
-#pragma clang fp contract(off)
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
-  const float rd = __builtin_fmaf(-dn, s, x), ru = __builtin_fmaf(-up, s, x);
-  float r = rd <= 0.0f ? dn : s;
-  r = ru > 0.0f ? up : r;
-  return r;
-}
-PT_DEV float rcp_core(float b) {  // the refined reciprocal the quotients of one denominator share
-#pragma clang fp contract(off)
-  const float r = __builtin_amdgcn_rcpf(b);
-  const float e = __builtin_fmaf(-b, r, 1.0f);
-  return __builtin_fmaf(e, r, r);
-}
-PT_DEV float quot_core(float a, float b, float r) {
-#pragma clang fp contract(off)
-  float q = a * r;
-  const float e2 = __builtin_fmaf(-b, q, a);
-  q = __builtin_fmaf(e2, r, q);
-  const float e3 = __builtin_fmaf(-b, q, a);
-  return __builtin_fmaf(e3, r, q);
-}
-PT_DEV float sqrt(float x) {
-  if (kGuarded && every_lane(sqrt_range(x))) return sqrt_core(x);
-  return __builtin_sqrtf(x);
-}
-PT_DEV float div(float a, float b) {
-  if (kGuarded && every_lane(div_range(a) && div_range(b))) return quot_core(a, b, rcp_core(b));
-  return a / b;
-}
-PT_DEV float rcp(float b) {
-  if (kGuarded && every_lane(div_range(b))) return quot_core(1.0f, b, rcp_core(b));
-  return 1.0f / b;
-}
-// 1 / sqrt(x) as the reference forms it: two correctly rounded operations.  One range test covers both.
-PT_DEV float rcp_sqrt(float x) {
-  if (kGuarded && every_lane(sqrt_range(x))) {
-    const float s = sqrt_core(x);
-    return quot_core(1.0f, s, rcp_core(s));
-  }
-  return 1.0f / __builtin_sqrtf(x);
-}
-// (a1 / b, a2 / b) and (1/x, 1/y, 1/z): one range test, and the two quotients of one denominator share its reciprocal
-PT_DEV void div2(float a1, float a2, float b, float& q1, float& q2) {
-  if (kGuarded && every_lane(div_range(a1) && div_range(a2) && div_range(b))) {
-    const float r = rcp_core(b);
-    q1 = quot_core(a1, b, r), q2 = quot_core(a2, b, r);
-    return;
-  }
-  q1 = a1 / b, q2 = a2 / b;
-}
-// (a.x, a.y, a.z) / b.  (Zero numerators stay outside the guarded range: the correction chain turns -0 / b into +0 — found by the
-// self-check.)
-PT_DEV void div3(float& x, float& y, float& z, float b) {
-  if (kGuarded && every_lane(div_range(x) && div_range(y) && div_range(z) && div_range(b))) {
-    const float r = rcp_core(b);
-    x = quot_core(x, b, r), y = quot_core(y, b, r), z = quot_core(z, b, r);
-    return;
-  }
-  x = x / b, y = y / b, z = z / b;
-}
-PT_DEV void rcp3(float x, float y, float z, float& rx, float& ry, float& rz) {
-  if (kGuarded && every_lane(div_range(x) && div_range(y) && div_range(z))) {
-    rx = quot_core(1.0f, x, rcp_core(x)), ry = quot_core(1.0f, y, rcp_core(y)), rz = quot_core(1.0f, z, rcp_core(z));
-    return;
-  }
-  rx = 1.0f / x, ry = 1.0f / y, rz = 1.0f / z;
-}
-}  // namespace ieee
+#include "pt_ieee.inc"
 // Exact a / n and a % n for 0 <= a < 2^30 and quotients below 2^15 (sample ids / tile pixels,
 // pixel index / image width): float estimate + one correction step either way, ~10 VALU instead of
 // the ~35 of a 32-bit integer division.  inv_n = 1.0f / n computed once per kernel.
@@ -955,236 +861,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
   }
 }
 
-// ───────────────────────────── shade ───────────────────────────────────────
-PT_DEV void local_frame(f3 n, f3& tangent, f3& bitangent) {  // pathtrace.cu:216-223
-  const bool a = __builtin_fabsf(n.x) > __builtin_fabsf(n.y);
-  tangent = normalize(a ? mk(n.z, 0.f, -n.x) : mk(0.f, -n.z, n.y));
-  bitangent = cross(n, tangent);
-}
-PT_DEV f3 sky_factor(f3 dir) {  // pathtrace.cu:360-362: skyColor * 0.5f
-  const float t = 0.5f * (dir.y + 1.0f);
-  const float w = (1.0f - t) * 1.0f;
-  return scl(mk(w + t * 0.5f, w + t * 0.7f, w + t * 1.0f), 0.5f);
-}
-
-struct ShadeIO {
-  f3 o, d, c;
-  bool alive;
-};
-// shadeAndExtendRays (pathtrace.cu:336-437) for a LIVE path, split in two so that the wave can
-// publish its survivor count (one atomic) while the expensive direction sampling still runs:
-//   shade_decide  everything that determines whether the path survives and its new throughput:
-//                 miss / emitter / Russian roulette / specular-vs-diffuse choice / colour product.
-//                 Consumes the RNG draws the reference consumes up to that point, in its order.
-//   shade_bounce  the new ray of a surviving path (remaining draws, sin/cos/acos).
-// A live path at depth d has exactly trace_depth - d bounces left, so remainingBounces is implied.
-// On `alive == false` the path retires with colour s.c; for a miss the sky factor has been applied
-// (trace_depth - depth) times, which is what the reference's repeated passes over dead paths do
-// (pathtrace.cu:356-366).
-struct Bounce {
-  uint32_t rng_x;   // minstd state after the draws consumed by shade_decide
-  int kind;         // 0 none, 1 specular, 2 diffuse
-  float roughness;
-};
-PT_DEV Bounce shade_decide(const ptd::Mat* __restrict__ mats, int trace_depth, int depth, uint32_t seed, float ht, int hmat,
-                           ShadeIO& s) {  // seed = iter_hash(iteration, depth) ^ utilhash(global pixel index), pathtrace.cu:205
-  Bounce bo;
-  bo.kind = 0;
-  bo.rng_x = 1u;
-  bo.roughness = 0.f;
-  s.alive = false;
-  if (ht < 0.0f) {
-    const f3 sky = sky_factor(s.d);
-    for (int k = depth; k < trace_depth; ++k) s.c = mul(s.c, sky);
-    return bo;
-  }
-  MinStd rng(seed);
-  const ptd::Mat* m = mats + hmat;
-  const f3 mcolor = mk(m->color[0], m->color[1], m->color[2]);
-  if (m->emittance > 0.0f) {
-    s.c = mul(s.c, scl(mcolor, m->emittance));
-    return bo;
-  }
-  if (depth > 3) {  // Russian roulette
-    const float q = __builtin_fmaxf(mcolor.x, __builtin_fmaxf(mcolor.y, mcolor.z));
-    if (rng.u01() > q) return bo;
-    if (kFastDiv) s.c = scl(s.c, __builtin_amdgcn_rcpf(q));
-    else ieee::div3(s.c.x, s.c.y, s.c.z, q);
-  }
-  const float reflectivity = m->reflective;
-  bo.roughness = 1.0f - m->refractive;
-  if (reflectivity > 0.0f && rng.u01() < reflectivity) {
-    bo.kind = 1;
-    s.c = mul(s.c, mk(m->spec[0], m->spec[1], m->spec[2]));
-  } else {
-    bo.kind = 2;
-    s.c = mul(s.c, mcolor);
-  }
-  bo.rng_x = rng.x;
-  // remainingBounces-- : the path survives unless this was its last allowed bounce (its new ray
-  // would never be traced, so it is not computed)
-  s.alive = (depth + 1) < trace_depth;
-  return bo;
-}
-// Direction sampling of the fast and fma modes: the same draws and the same formulas, evaluated in float only.
-//   The trigonometric arguments are taken in REVOLUTIONS — sin(2*pi*u) of the draw u itself, and the specular angle
-//   roughness*u1*pi/2 = roughness*u1/4 revolutions — so no 2*pi*u is rounded to float first (the reference rounds it, then calls sinf);
-//   diffuse: cos(theta) = sqrt(1 - u1) =: s and sin(theta) = sin(acos(s)) = sqrt(1 - s*s) (one FMA keeps 1 - s*s exact
-//   to one rounding), so neither acos nor a sincos of theta is evaluated.
-//   HW (fast): v_sin_f32 / v_cos_f32 take revolutions directly, v_sqrt_f32.
-//   !HW (fma): IEEE square roots and ptmath::sincos_rev (float polynomials, <= 1.6 ulp: the accuracy class of the sinf / cosf the
-//   reference runs on under nvcc, which documents 2 ulp); the specular evaluations only when the wave holds a specular lane.
-//   Round 3: the fma mode used to share the exact mode's sampling (fdlibm acosf + three double-reduced sincos, 900 issue cycles a
-//   group); it is held to the tolerance, not to bit-equality, and the tolerance does not see the difference (tests/test_gpu_arith.py).
-template <bool HW>
-PT_DEV void shade_bounce_float(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
-  MinStd rng(1u);
-  rng.x = bo.rng_x;
-  const bool spec = bo.kind == 1;
-  const float r1 = rng.u01(), r2 = rng.u01(), r3 = rng.u01();
-  const f3 refl = madd(hn, -2.0f * dot(s.d, hn), s.d);
-  const f3 f = spec ? refl : hn;
-  const float rev = bo.roughness * r1 * 0.25f;
-  const float ct = HW ? __builtin_amdgcn_sqrtf(1.0f - r1) : __builtin_sqrtf(1.0f - r1);
-  const float st2 = __builtin_fmaxf(fma_(-ct, ct, 1.0f), 0.0f);
-  const float st = HW ? __builtin_amdgcn_sqrtf(st2) : __builtin_sqrtf(st2);
-  float sA = 0.0f, cA = 1.0f, c1, s2;
-  if (HW) {
-    sA = __builtin_amdgcn_sinf(rev), cA = __builtin_amdgcn_cosf(rev);
-    c1 = __builtin_amdgcn_cosf(r2);
-    s2 = __builtin_amdgcn_sinf(spec ? r3 : r2);
-  } else {
-    ptmath::sincos_rev(r2, &s2, &c1);
-    if (ballot(spec)) {  // wave-uniform
-      float s3, c3;
-      ptmath::sincos_rev(rev, &sA, &cA);
-      ptmath::sincos_rev(r3, &s3, &c3);
-      s2 = spec ? s3 : s2;
-    }
-  }
-  const float sX = spec ? sA : st;
-  const float cX = spec ? cA : ct;
-  const float x = sX * c1, z = sX * s2, y = cX;
-  f3 tangent, bitangent;
-  local_frame(f, tangent, bitangent);
-  const f3 pert = normalize(madd(tangent, x, madd(f, y, scl(bitangent, z))));
-  const bool perturb = !spec || bo.roughness > 0.0f;
-  s.o = madd(hn, 0.001f, hp);
-  s.d = perturb ? pert : refl;
-}
-PT_DEV void shade_bounce(const Bounce& bo, f3 hn, f3 hp, ShadeIO& s) {
-  if (kFastTrig) return shade_bounce_float<true>(bo, hn, hp, s);
-  if (kFloatTrig) return shade_bounce_float<false>(bo, hn, hp, s);
-  // The specular branch (pathtrace.cu:402-422) and the diffuse branch (:424-435, :225-238) have the
-  // same shape — a frame around an axis f, three trigonometric evaluations, normalize(t*x + f*y + b*z)
-  // — so both are evaluated by ONE instruction stream with per-lane operands instead of two divergent
-  // branches executed back to back (a wave almost always holds both kinds).  Operations and their
-  // order per lane are exactly the reference's:
-  //   specular: f = reflect(d, n); angle = float(roughness*u1 * M_PI * 0.5f) [double product];
-  //             x = float(sin(angle) * cos(2.0f*M_PI*u2)) [double], y = cos(angle),
-  //             z = float(sin(angle) * sin(2.0f*M_PI*u3)) [double]
-  //   diffuse:  f = n; theta = acos(sqrt(1-u1)); phi = float(2.0f*M_PI*u2) [double product];
-  //             x = sin(theta)*cos(phi), y = cos(theta), z = sin(theta)*sin(phi)   [float]
-  const double kPi = 3.14159265358979323846;
-  MinStd rng(1u);
-  rng.x = bo.rng_x;
-  const bool spec = bo.kind == 1;
-  const float r1 = rng.u01(), r2 = rng.u01(), r3 = rng.u01();  // diffuse consumes only two; the engine dies here
-  const f3 refl = sub(s.d, scl(hn, 2.0f * dot(s.d, hn)));     // reflect(): incident - 2*dot(incident, n)*n
-  const f3 f = spec ? refl : hn;
-  const float angle = (float)((double)(bo.roughness * r1) * kPi * (double)0.5f);
-  const float theta = ptmath::acosf32(__builtin_sqrtf(1.0f - r1));
-  const float phi = (float)((double)2.0f * kPi * (double)r2);
-  const float X = spec ? angle : theta;
-  const double Y1 = spec ? (double)2.0f * kPi * (double)r2 : (double)phi;
-  const double Y2 = spec ? (double)2.0f * kPi * (double)r3 : (double)phi;
-  float sX, cX;
-  ptmath::sincosf32(X, &sX, &cX);
-  const float c1 = ptmath::cos_r(Y1);
-  const float s2 = ptmath::sin_r(Y2);
-  // specular: float(double(sX) * double(c1)) — the double product of two floats is exact, so it rounds
-  // to the same value as the float product the diffuse branch forms
-  const float x = sX * c1;
-  const float z = sX * s2;
-  const float y = cX;
-  f3 tangent, bitangent;
-  local_frame(f, tangent, bitangent);
-  const f3 pert = normalize(add(add(scl(tangent, x), scl(f, y)), scl(bitangent, z)));
-  const bool perturb = !spec || bo.roughness > 0.0f;  // a perfect mirror keeps the reflected direction
-  s.o = add(hp, scl(hn, 0.001f));
-  s.d = perturb ? pert : refl;
-}
-
-
-__global__ __launch_bounds__(kBlock) void k_shade(SceneTables sc, BatchInfo b, int depth, ptd::Queues qs,
-                                                  const int32_t* __restrict__ cnt_in, int32_t* __restrict__ cnt_out,
-                                                  ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                                                  ptd::RetireBuf ret) {
-  extern __shared__ float4 lds_raw[];
-  char* lds = reinterpret_cast<char*>(lds_raw);  // [materials][iteration hashes]
-  stage16(lds, sc.mats, sc.num_mats * (int)sizeof(ptd::Mat));
-  uint32_t* ihash = reinterpret_cast<uint32_t*>(lds + ((sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15));
-  iter_hash_fill(ihash, sc, b, depth);
-  __syncthreads();
-  const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds);
-
-  const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  const int lane = lane_id();
-  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const Retire rt = retire_of(ret, q);
-  const int n_q = cnt_in[(size_t)q * qs.cnt_stride];
-  const int64_t HS = hits.stride;
-  const int64_t qbase = (int64_t)q * qs.cap;
-  // inputs of one path; the next group's are loaded (branch-free, index clamped into the queue's own
-  // region) while the current group is shaded
-  struct In {
-    PathTag tag;
-    int hmat;
-    float ht;
-    f3 hn, hp, d, c;
-  };
-  const int last = qs.cap - 64 + lane;
-  auto load = [&](int i) {
-    In v;
-    const int64_t at = qbase + min(i, last);
-    v.ht = hits.t[at];
-    v.hn = mk(hits.n[at], hits.n[HS + at], hits.n[2 * HS + at]);
-    v.hmat = hits.mat[at];
-    v.hp = mk(hits.p[at], hits.p[HS + at], hits.p[2 * HS + at]);
-    path_load_tail(in, at, v.d, v.c, v.tag);
-    return v;
-  };
-  In nx = load(r * 64 + lane);
-  for (int j = r; j * 64 < n_q; j += wq) {
-    const int i = j * 64 + lane;
-    const bool valid = i < n_q;
-    const In cur = nx;
-    nx = load((j + wq) * 64 + lane);
-    ShadeIO s;
-    s.o = mk(0.f, 0.f, 0.f);
-    s.d = cur.d;
-    s.c = cur.c;
-    s.alive = false;
-    Bounce bo;
-    bo.kind = 0;
-    int k, pl;
-    sample_of(cur.tag, b, k, pl);
-    if (valid) bo = shade_decide(mats, b.trace_depth, depth, path_seed(k, pl, ihash, sc, b, depth), cur.ht, cur.hmat, s);
-    // dead lanes: one record each at the front of region (q, k); survivors: ballot + popcount, ONE atomic per wave on the
-    // queue's counter of the next depth, compacted stores
-    retire_append(rt, valid && !s.alive, k, pl, s.c);
-    const bool alive = valid && s.alive;
-    const unsigned long long live = ballot(alive);
-    int base = 0;
-    if (live && lane == 0) base = atomicAdd(&cnt_out[(size_t)q * qs.cnt_stride], (int)__popcll(live));
-    if (alive) shade_bounce(bo, cur.hn, cur.hp, s);
-    if (live) {
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (alive) path_store(out, qbase + base + rank_in(live), s.o, s.d, s.c, cur.tag);
-    }
-  }
-}
-
+#include "pt_shade.inc"
 // ── candidate ring with carry-over (fused kernels) ────────────────────────────────────────
 // In the fused kernels the candidates of consecutive groups share one per-wave FIFO ring: a primitive-
 // test chunk is run whenever 64 entries are pending, and what is left at the end of a group's search
@@ -1416,235 +1093,7 @@ PT_DEV void carry_drain_to(Carry<SMALL, NPAR>& c, int mark, int lane, const ptd:
   while (c.processed - mark < 0) carry_chunk<SMALL, NPAR, EX, false, QO>(c, min(64, c.count), lane, nodes, geoms);
 }
 
-// ── uniform grid walk (SceneTables::grid_*; large scenes, when faster than the BVH scan) ───────────────────────────────
-// Second ring of a wave: cell records a ray came across, waiting for their leaf-box test.  Entry: record index << 10 |
-// direction the ray entered the cell from (0..5 = through its -x, +x, -y, +y, -z, +z face, 7 = first cell) << 7 |
-// group parity << 6 | owner lane.
-constexpr int kCellRing = 256;  // entries (power of two): what is left of a step (< 64) + what a step files (<= 192 at once)
-struct CellRing {
-  uint32_t* ent;  // [kCellRing]
-  int head, count;
-  float* rinv;    // [rinv_planes][64] reciprocal direction of each lane's ray in the mode's arithmetic (+ -o * that: fast)
-};
-// What the leaf-box tests need of a ray is computed once per ray and kept in LDS (CellRing::rinv) instead of once per record
-// (a group tests ~950 records, 15 per ray): the reciprocal direction — three IEEE divides in the exact and fma arithmetic —
-// and, where the slab test has the FMA form t = plane * i + n (fast), n = -o * i as well, so that a record's test reads six
-// values and computes no reciprocal.  (Round 2 measured the stored reciprocals 34 % slower for the fast build of the kernel
-// as it was then; round 3, with the retirement and filing changes in: 3.4 % faster, `n` included 6 %.)
-template <bool EX>
-constexpr int rinv_planes() { return (EX || !kFastSlab) ? 3 : 6; }
-template <bool EX>
-constexpr int grid_wave_bytes() { return carry_bytes<false, 1>() + kCellRing * 4 + kRing * 4 + rinv_planes<EX>() * 64 * 4; }  // Carry + cell ring + Carry::gix + CellRing::rinv
-// Exclusive prefix sum over the wave of a small count per lane, and the total: a Hillis-Steele scan on the DPP network —
-// four row_shr steps scan each row of 16 lanes, row_bcast:15 / :31 carry the row totals over — six v_add_u32_dpp instead of
-// the six ballots + twelve mbcnt + six shift-adds of a bit-sliced count (round 2; the walk loop runs this once per cell step).
-// All 64 lanes must be active (the callers' control flow is wave-uniform).
-PT_DEV int wave_prefix6(int v, int& total) {
-  int x = v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1, zero shifted in
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8: inclusive scan of each row
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-  total = __builtin_amdgcn_readlane(x, 63);
-  return x - v;
-}
-// Leaf-box tests (the mode's slab arithmetic: these decide, exactly like the reference's walk, which primitives a ray is
-// tested against) for the first n (<= 64) pending records; passing leaves go to the primitive ring.  A leaf that is also
-// listed in the cell the ray came from was handled there: a box occupies a block of cells and the ray's cells inside a
-// block are consecutive.  Wave-uniform control flow.
-template <int NPAR, bool EX = false>
-PT_DEV void grid_filter(Carry<false, NPAR>& c, CellRing& cr, int n, const SceneTables& sc, int lane,
-                        const ptd::Node* __restrict__ nodes, const ptd::Geom* __restrict__ geoms) {
-  const bool valid = lane < n;
-  PT_STAT(4, 1);
-  PT_STAT(5, n);
-  const uint32_t entry = cr.ent[(cr.head + lane) & (kCellRing - 1)];
-  const int src = (int)(entry & 63u);
-  const int par = (int)((entry >> 6) & 1u);
-  const int from = (int)((entry >> 7) & 7u);
-  const uint32_t item = valid ? entry >> 10 : 0u;
-  const float4 NA = reinterpret_cast<const float4*>(sc.grid_items)[2 * item];      // bmin.xyz, bmax.x
-  const float4 NB = reinterpret_cast<const float4*>(sc.grid_items)[2 * item + 1];  // bmax.yz, leaf, neighbour bits
-  RayInv ri;  // as ray_inv() builds it, from the values stored once per ray
-  f3 ro = mk(0.f, 0.f, 0.f);
-  ri.ix = cr.rinv[0 * 64 + src], ri.iy = cr.rinv[1 * 64 + src], ri.iz = cr.rinv[2 * 64 + src];
-  ri.sx = ri.ix < 0.0f, ri.sy = ri.iy < 0.0f, ri.sz = ri.iz < 0.0f;
-  if (rinv_planes<EX>() == 6) {  // FMA form: the origin itself is not needed
-    ri.nx = cr.rinv[3 * 64 + src], ri.ny = cr.rinv[4 * 64 + src], ri.nz = cr.rinv[5 * 64 + src];
-  } else {
-    const float* ray = c.ray + par * 6 * 64 + src;
-    ro = mk(ray[0 * 64], ray[1 * 64], ray[2 * 64]);
-    ri.nx = -ro.x * ri.ix, ri.ny = -ro.y * ri.iy, ri.nz = -ro.z * ri.iz;
-  }
-  const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + src) + 1]) + sc.cull_margin;
-  float tn;
-  const uint32_t bits = __float_as_uint(NB.w);  // neighbour bits | primitive type << 6 | geom index << 8
-  const bool seen = ((bits & 63u) >> from) & 1u;  // from == 7: first cell of a walk, nothing seen
-  // no short-circuit: with `&&` the compiler fetches the record's last 8 bytes first, branches on `seen`, and only then fetches
-  // the box — two dependent memory round trips per chunk and 2.6 load instructions per record instead of 2
-  const bool box = Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn);
-  const bool pass = (int)valid & (int)!seen & (int)box & (int)!(tn > bt);
-  cr.head = (cr.head + n) & (kCellRing - 1);
-  cr.count -= n;
-#ifdef PT_WALK_STATS
-  const int st_seen = __popcll(ballot(valid && seen)), st_pass = __popcll(ballot(pass));
-  const int st_box = __popcll(ballot(valid && !seen && Ar<EX>::slab_t(ro, ri, NA.x, NA.y, NA.z, NA.w, NB.x, NB.y, tn)));
-  PT_STAT(10, st_seen);
-  PT_STAT(11, st_pass);
-  PT_STAT(12, st_box);
-#endif
-  carry_append<false, NPAR, EX, true>(c, pass, __float_as_uint(NB.z), par, src, lane, nodes, geoms,
-                                      (bits >> 8) | (((bits >> 6) & 3u) << 30));
-}
-// State of a lane's cell walk (3D-DDA): the distance along the ray of the next cell boundary per axis, the distance
-// between boundaries, the current cell.  A walk ends by distance alone (te > t_end, the grid's far side): the boundary
-// distances accumulate rounding, so the decision at the exit face can come a step late — up to three steps at a corner of
-// the grid — and the cell index then leaves the grid by at most one cell per axis, i.e. by < rx * ry + rx + 2 entries of
-// the cell table: the host pads the table with that many empty cells on both sides (pt_api.cpp), and a wrapped index
-// inside the table only adds records to test (round 2 counted the cells left per axis instead: 3 registers and 6
-// instructions per step).
-struct CellWalk {
-  float tx, ty, tz, ddx, ddy, ddz;
-  int px, py, pz;  // per axis: cell-index step << 3 | face the next cell is entered through (0..5 = its -x, +x, -y, +y, -z, +z face)
-  int idx;
-  float te, t_end;  // entry distance of the current cell; the walk covers [te, t_end]
-  uint32_t from;    // face the current cell was entered through (grid_filter), 7: first cell of a walk
-  int own;          // lane that owns the ray
-  bool on;
-};
-// Start a walk of ray (o, d) over the part [t_from, t_to] of its span inside the grid.  Fast float arithmetic in every
-// mode: the walk only has to reach every cell the ray touches, which the padding of the cell lists guarantees.
-PT_DEV void walk_start(const SceneTables& sc, f3 o, f3 d, float t_from, float t_to, bool want, int own, CellWalk& w) {
-  const float dx = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), 1e-20f), d.x);
-  const float dy = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), 1e-20f), d.y);
-  const float dz = __builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), 1e-20f), d.z);
-  const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
-  const int rx = sc.grid_res[0], ry = sc.grid_res[1], rz = sc.grid_res[2];
-  const float gx = sc.grid_min[0], gy = sc.grid_min[1], gz = sc.grid_min[2];
-  const float csx = sc.grid_cs[0], csy = sc.grid_cs[1], csz = sc.grid_cs[2];
-  const float ax0 = (gx - o.x) * ix, ax1 = (gx + csx * (float)rx - o.x) * ix;
-  const float ay0 = (gy - o.y) * iy, ay1 = (gy + csy * (float)ry - o.y) * iy;
-  const float az0 = (gz - o.z) * iz, az1 = (gz + csz * (float)rz - o.z) * iz;
-  const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax0, ax1), __builtin_fminf(ay0, ay1)),
-                                     __builtin_fmaxf(__builtin_fminf(az0, az1), t_from));
-  const float t_out = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax0, ax1), __builtin_fmaxf(ay0, ay1)),
-                                      __builtin_fminf(__builtin_fmaxf(az0, az1), t_to));
-  w.on = want && t_out >= t_in;
-  const float px = o.x + d.x * t_in, py = o.y + d.y * t_in, pz = o.z + d.z * t_in;
-  const int cx = min(max((int)__builtin_floorf((px - gx) * sc.grid_inv_cs[0]), 0), rx - 1);
-  const int cy = min(max((int)__builtin_floorf((py - gy) * sc.grid_inv_cs[1]), 0), ry - 1);
-  const int cz = min(max((int)__builtin_floorf((pz - gz) * sc.grid_inv_cs[2]), 0), rz - 1);
-  const bool fx = dx >= 0.0f, fy = dy >= 0.0f, fz = dz >= 0.0f;  // moving towards +x / +y / +z
-  w.tx = (gx + csx * (float)(cx + (fx ? 1 : 0)) - o.x) * ix;
-  w.ty = (gy + csy * (float)(cy + (fy ? 1 : 0)) - o.y) * iy;
-  w.tz = (gz + csz * (float)(cz + (fz ? 1 : 0)) - o.z) * iz;
-  w.ddx = csx * __builtin_fabsf(ix), w.ddy = csy * __builtin_fabsf(iy), w.ddz = csz * __builtin_fabsf(iz);
-  const int rxy = rx * ry;
-  w.px = fx ? 8 + 0 : -8 + 1;  // moving +x: the next cell is entered through its -x face  (step = word >> 3, face = word & 7)
-  w.py = fy ? 8 * rx + 2 : -8 * rx + 3;
-  w.pz = fz ? 8 * rxy + 4 : -8 * rxy + 5;
-  w.idx = cx + rx * (cy + ry * cz);
-  w.te = t_in;
-  w.t_end = t_out;
-  w.from = 7u;
-  w.own = own;
-}
-// Candidate search of one group through the grid: every lane walks its own ray cell by cell, files the records of each
-// cell in the cell ring, and stops at the far side of the grid or once the next cell starts beyond the ray's best hit so
-// far (the closer-hit cull of the subtree scans, same margin + the padding).  Rays hit after 6 cells on average but the
-// longest of 64 walks takes 26, so once few lanes are still walking their remaining spans are cut into equal parts and
-// dealt to all 64 lanes (candidates are filed under the lane that owns the ray, as with the work stealing of the
-// subtree scans; the parts overlap by a cell, which costs a repeated test and changes nothing).
-#ifndef PT_GRID_SPLIT
-#define PT_GRID_SPLIT 16
-#endif
-constexpr int kGridSplit = PT_GRID_SPLIT;  // lanes still walking when the remaining spans are dealt out (0: never)
-template <int NPAR, bool EX = false>
-PT_DEV void grid_search(Carry<false, NPAR>& c, CellRing& cr, const SceneTables& sc, const ptd::Node* __restrict__ nodes,
-                        const ptd::Geom* __restrict__ geoms, f3 o, f3 d, bool valid, int lane, int par) {
-  float* rays = c.ray + par * 6 * 64;
-  rays[0 * 64 + lane] = o.x, rays[1 * 64 + lane] = o.y, rays[2 * 64 + lane] = o.z;
-  rays[3 * 64 + lane] = d.x, rays[4 * 64 + lane] = d.y, rays[5 * 64 + lane] = d.z;
-  {
-    const RayInv ri = Ar<EX>::ray_inv(d, o);
-    cr.rinv[0 * 64 + lane] = ri.ix, cr.rinv[1 * 64 + lane] = ri.iy, cr.rinv[2 * 64 + lane] = ri.iz;
-    if (rinv_planes<EX>() == 6) cr.rinv[3 * 64 + lane] = ri.nx, cr.rinv[4 * 64 + lane] = ri.ny, cr.rinv[5 * 64 + lane] = ri.nz;
-  }
-  CellWalk w;
-  PT_STAT(0, 1);
-  walk_start(sc, o, d, 0.0f, FLT_MAX, valid, lane, w);
-  const float slack = sc.cull_margin + 2.0f * sc.grid_pad;
-  int splits = 0;
-  while (true) {
-    const float bt = __uint_as_float(reinterpret_cast<const uint32_t*>(c.best)[2 * (par * 64 + w.own) + 1]) + slack;
-    w.on = w.on && !(w.te > bt) && !(w.te > w.t_end);
-    const unsigned long long M = ballot(w.on);
-    if (!M) break;
-    PT_STAT(1, 1);
-    PT_STAT(2, __popcll(M));
-    if (kGridSplit > 0 && splits < 2 && __popcll(M) <= kGridSplit) {
-      ++splits;
-      const int n_on = __popcll(M);
-      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0));
-      if (w.on) c.slot[rank] = lane;
-      const int k = 64 / n_on;
-      const int r = lane / k, seg = lane - r * k;
-      const bool take = r < n_on;
-      const int donor = c.slot[take ? r : 0];
-      const float d_te = bperm(donor, w.te), d_end = bperm(donor, w.t_end);
-      const int d_own = __builtin_amdgcn_ds_bpermute(donor << 2, w.own);
-      const f3 so = mk(rays[0 * 64 + d_own], rays[1 * 64 + d_own], rays[2 * 64 + d_own]);
-      const f3 sd = mk(rays[3 * 64 + d_own], rays[4 * 64 + d_own], rays[5 * 64 + d_own]);
-      const float part = (d_end - d_te) / (float)k;
-      const float ta = d_te + part * (float)seg;
-      const float tb = seg == k - 1 ? d_end : ta + part;
-      walk_start(sc, so, sd, ta, tb, take, d_own, w);
-    }
-    const uint2 se = w.on ? *reinterpret_cast<const uint2*>(sc.grid_start + w.idx) : make_uint2(0u, 0u);  // 4-byte aligned pair
-    const uint32_t tag = (w.from << 7) | ((uint32_t)par << 6) | (uint32_t)w.own;
-    // File the cells' records, a cell's records next to each other: the lanes of a box-test chunk then read neighbouring
-    // 32-byte records (one L1 access per 128-byte line instead of one per lane — the L1's access rate is what bounds
-    // this kernel).  Ring positions from a prefix sum over the lanes' list lengths; a step files at most 192 records at
-    // once, a lane up to 63 (longer lists and later lanes take another turn).
-    uint32_t it = se.x;
-    while (true) {
-      const int want = (int)min(se.y - it, 63u);
-      int total;
-      const int pre = wave_prefix6(want, total);
-      if (total == 0) break;
-      const bool now = pre + want <= kCellRing - 64;
-      const int take = now ? want : 0;
-#ifdef PT_WALK_STATS
-      const int st_trips = wave_max_stat(take), st_lanes = __popcll(ballot(take > 0));
-      PT_STAT(3, 1);
-      PT_STAT(8, st_trips);
-      PT_STAT(9, st_lanes);
-#endif
-      const int base = cr.head + cr.count + pre;
-      for (int j = 0; j < take; ++j) cr.ent[(base + j) & (kCellRing - 1)] = ((it + (uint32_t)j) << 10) | tag;
-      it += (uint32_t)take;
-      // the lanes that filed are a prefix of the lanes (pre grows with the lane index): the last one knows the sum
-      const unsigned long long nm = ballot(now);
-      if (nm) cr.count += __builtin_amdgcn_readlane(pre + want, 63 - __builtin_clzll(nm));
-      while (cr.count >= 64) grid_filter<NPAR, EX>(c, cr, 64, sc, lane, nodes, geoms);
-      if (!ballot(it != se.y)) break;  // the usual case: every list went in at once — no second pass to find that out
-    }
-    // next cell: through the nearest boundary
-    w.te = __builtin_fminf(__builtin_fminf(w.tx, w.ty), w.tz);
-    const bool ax = w.tx == w.te;
-    const bool ay = !ax && w.ty == w.te;
-    const int step = ax ? w.px : ay ? w.py : w.pz;
-    w.idx += step >> 3;
-    w.from = (uint32_t)step & 7u;
-    if (ax) w.tx += w.ddx;
-    else if (ay) w.ty += w.ddy;
-    else w.tz += w.ddz;
-  }
-  while (cr.count > 0) grid_filter<NPAR, EX>(c, cr, min(64, cr.count), sc, lane, nodes, geoms);
-}
-
+#include "pt_grid.inc"
 // ── depth 0 fused: generateRayFromCamera + computeIntersections + shadeAndExtendRays ────────
 // Primary rays are a pure function of the sample id, so depth 0 needs no path state in memory at
 // all: the ray is built in registers, traced with the same wave-cooperative search, shaded, and
@@ -2345,389 +1794,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_stage(SceneTables sc, int trac
   }
 }
 
-// ───────────────────────────── gather / stats / preview ────────────────────
-// finalGather (pathtrace.cu:439-444) from the retirement records: one workgroup per queue.  The queue owns the same
-// pixels in every iteration (ptd::Queues), at most kCollectPixels of them per pass; for k = 0, 1, ... region (q, k) — one
-// record per pixel of the queue, contiguous, exactly full (pt_device.h RetireBuf) — is read front to back with coalesced
-// 16-byte loads and dropped into an LDS tile indexed by pixel, and every thread adds the tile to the accumulators of its
-// pixels: image[p] = (((image[p] + c_0) + c_1) + ...), the order in which successive finalGather launches would have added
-// them.  Nothing is scattered through memory: the regions are read once, the image is read and written once.  Queues
-// with more pixels than a tile (frames beyond 4K at Q = 256 .. 1024) take several passes over their records.
-constexpr int kCollectThreads = 1024;
-constexpr int kCollectPPT = 8;                                // pixels (and records) per thread and pass
-constexpr int kCollectPixels = kCollectPPT * kCollectThreads;  // 8192 pixels = 128 chunks: 96 KB of LDS
-__host__ __device__ inline int collect_lds_bytes() { return kCollectPixels * 12; }
-// records i0 + t, i0 + t + 1024, ... of a region, eight per thread
-struct CollectChunk {
-  ptd::Word4 v[kCollectPPT];
-};
-PT_DEV void collect_load(const ptd::Word4* rec, int n, int i0, CollectChunk& c) {
-#pragma unroll
-  for (int u = 0; u < kCollectPPT; ++u) {
-    const int i = i0 + u * kCollectThreads + (int)threadIdx.x;
-    c.v[u] = rec[i < n ? i : (n > 0 ? n - 1 : 0)];
-  }
-}
-// (g0, g1: slots of the region that hold no record — the unused tail of the sub-region with the tile's partial last chunk)
-PT_DEV void collect_scatter(const CollectChunk& c, int n, int i0, int g0, int g1, int Q, float inv_q, int first, float* tile) {
-#pragma unroll
-  for (int u = 0; u < kCollectPPT; ++u) {
-    const int i = i0 + u * kCollectThreads + (int)threadIdx.x;
-    const int pl = __float_as_int(c.v[u].w);
-    int jj, qq;
-    divmod(pl >> 6, Q, inv_q, jj, qq);
-    const int li = jj * 64 + (pl & 63) - first;
-    if (i < n && !(i >= g0 && i < g1) && li >= 0 && li < kCollectPixels) tile[3 * li] = c.v[u].x, tile[3 * li + 1] = c.v[u].y, tile[3 * li + 2] = c.v[u].z;
-  }
-}
-__global__ __launch_bounds__(kCollectThreads) void k_collect(BatchInfo b, ptd::Queues qs, ptd::RetireBuf ret, float* __restrict__ image) {
-  extern __shared__ float4 lds_raw[];
-  float* tile = reinterpret_cast<float*>(lds_raw);  // [kCollectPixels][3]
-  const int q = blockIdx.x;
-  const QueueShare sh = queue_share(b, qs, q);
-  const float inv_q = 1.0f / (float)qs.Q;
-  const ptd::Word4* rec = ret.rec + (int64_t)q * ret.kmax * ret.seg_cap;  // region (q, 0)
-  // Records per region: flat form — my_pixels, appended from the front; otherwise one slot per pixel of the queue's my_nq chunks,
-  // every one filled except the last (64 - N % 64) slots of the sub-region that holds the tile's partial last chunk.
-  int n = sh.my_pixels, g0 = 0, g1 = 0;
-  if (!b.flat) {
-    n = sh.my_nq * 64;
-    const int missing = n - sh.my_pixels;
-    if (missing > 0) {
-      const int quo = sh.my_nq / ret.wq0, rem = sh.my_nq % ret.wq0, rho = (sh.my_nq - 1) % ret.wq0;
-      g1 = (sub_offset(quo, rem, rho) + sub_chunks(quo, rem, rho)) * 64;
-      g0 = g1 - missing;
-    }
-  }
-  for (int first = 0; first < sh.my_nq * 64; first += kCollectPixels) {  // one pass per kCollectPixels of the queue's pixels
-    float acc[kCollectPPT][3];
-    // thread t owns the queue pixels first + t + kCollectThreads * m: chunk jj = index >> 6 is tile chunk q + jj * Q
-#pragma unroll
-    for (int m = 0; m < kCollectPPT; ++m) {
-      const int li = first + threadIdx.x + kCollectThreads * m;
-      const int pl = (q + (li >> 6) * qs.Q) * 64 + (li & 63);
-      const bool mine = li < sh.my_nq * 64 && pl < b.N;
-      acc[m][0] = mine ? image[3 * (int64_t)pl] : 0.f, acc[m][1] = mine ? image[3 * (int64_t)pl + 1] : 0.f, acc[m][2] = mine ? image[3 * (int64_t)pl + 2] : 0.f;
-    }
-    // software pipeline: the first 8192 records of iteration k + 1 are in flight while iteration k is summed (the tile is
-    // reused every iteration, so the two barriers per iteration stay)
-    CollectChunk c;
-    collect_load(rec, n, 0, c);
-    for (int k = 0; k < b.K; ++k) {
-      collect_scatter(c, n, 0, g0, g1, qs.Q, inv_q, first, tile);
-      for (int i0 = kCollectPixels; i0 < n; i0 += kCollectPixels) {  // regions longer than one chunk (several passes only)
-        collect_load(rec + (int64_t)k * ret.seg_cap, n, i0, c);
-        collect_scatter(c, n, i0, g0, g1, qs.Q, inv_q, first, tile);
-      }
-      if (k + 1 < b.K) collect_load(rec + (int64_t)(k + 1) * ret.seg_cap, n, 0, c);
-      __syncthreads();
-#pragma unroll
-      for (int m = 0; m < kCollectPPT; ++m) {
-        const int li = threadIdx.x + kCollectThreads * m;  // every pixel of the queue retires exactly once per iteration: no stale entries are read
-        acc[m][0] += tile[3 * li], acc[m][1] += tile[3 * li + 1], acc[m][2] += tile[3 * li + 2];
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int m = 0; m < kCollectPPT; ++m) {
-      const int li = first + threadIdx.x + kCollectThreads * m;
-      const int pl = (q + (li >> 6) * qs.Q) * 64 + (li & 63);
-      if (li < sh.my_nq * 64 && pl < b.N) image[3 * (int64_t)pl] = acc[m][0], image[3 * (int64_t)pl + 1] = acc[m][1], image[3 * (int64_t)pl + 2] = acc[m][2];
-    }
-  }
-  // the records are consumed: zero counters for the next batch
-  for (int i = threadIdx.x; i < ret.kmax; i += kCollectThreads) ret.cnt[(int64_t)q * ret.kmax + i] = 0ull;
-}
-
-__global__ void k_count_stats(ptd::Queues qs, int32_t* __restrict__ cnt, int depth_count,
-                              unsigned long long* __restrict__ stats) {
-  // one block per counter row (depth 0 .. depth_count): add the row's fill levels to the statistics and leave the
-  // row zeroed for the next batch (saves a memset launch per batch)
-  const int d = blockIdx.x;
-  if (d > depth_count) return;
-  unsigned long long acc = 0;
-  for (int q = threadIdx.x; q < qs.Q; q += blockDim.x) {
-    int32_t* c = &cnt[((size_t)d * qs.Q + q) * qs.cnt_stride];
-    acc += (unsigned long long)*c;
-    *c = 0;
-  }
-  if (d == depth_count) return;  // the row behind the last depth only needs the reset
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  __shared__ unsigned long long part[kWavesPerBlock];
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long t = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
-    stats[d] += t;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_preview(int n, int iterations, const float* __restrict__ image,
-                                                    uchar4* __restrict__ rgba) {
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-    const float inv = (float)iterations;
-    float v[3];
-    for (int c = 0; c < 3; ++c) {
-      const float pix = __builtin_powf(image[3 * (int64_t)p + c] / inv, 1.0f / 2.2f);
-      int q = (int)(pix * 255.0f);
-      v[c] = (float)(q < 0 ? 0 : (q > 255 ? 255 : q));
-    }
-    rgba[p] = make_uchar4((unsigned char)v[0], (unsigned char)v[1], (unsigned char)v[2], 0);
-  }
-}
-
-// saveImage (main.cpp:86-107) + image::savePNG's conversion (image.cpp:22-39) on the device, for tiles made of whole
-// image rows: tile pixel p = x + ty*W becomes three bytes at the x-mirrored position (W - 1 - x) + ty*W of its row,
-// each (unsigned char)(clamp(sum / samples, 0, 1) * 255) — truncation, no gamma, NaN -> 0 like pt_image.cpp's to_u8.
-// Write-out then moves 3 B per pixel over PCIe / xGMI instead of 12.
-__global__ __launch_bounds__(kBlock) void k_save_u8(int n, int width, float samples, const float* __restrict__ image,
-                                                    uint8_t* __restrict__ rgb8) {
-  const float inv_w = 1.0f / (float)width;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-    int ty, x;
-    divmod(p, width, inv_w, ty, x);
-    uint8_t* dst = rgb8 + 3 * ((int64_t)ty * width + (width - 1 - x));
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float v = image[3 * (int64_t)p + c] / samples;  // IEEE divide in every mode: bytes equal the host writer's
-      float m = v > 0.0f ? v : 0.0f;
-      m = m < 1.0f ? m : 1.0f;
-      dst[c] = (uint8_t)(m * 255.f);
-    }
-  }
-}
-
-inline int round16(int x) { return (x + 15) & ~15; }
-
-// ───────────────────────────── launch wrappers ─────────────────────────────
-int fused_lds_bytes(const SceneTables& sc, bool in_lds, int wave_lds, bool primary = false) {
-  int bytes = sc.num_top * (int)sizeof(ptd::TopEntry) + round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * wave_lds + iter_hash_entries(sc) * 4;
-  if (in_lds) bytes += round16(sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom));
-  if (primary) bytes += sc.num_top * (int)sizeof(ptd::TopEntry) + (in_lds ? round16(sc.num_geoms * 12) : 0);  // camera-relative copies
-  return bytes;
-}
-int table_bytes(const SceneTables& sc) { return sc.num_nodes * (int)sizeof(ptd::Node) + sc.num_geoms * (int)sizeof(ptd::Geom); }
-bool tables_in_lds(const SceneTables& sc) { return table_bytes(sc) <= sc.lds_table_bytes; }
-// k_paths' search form: 2 = uniform grid walk, 0 = scene tables in LDS (every leaf a top entry), 1 = top list + subtree scans
-int paths_mode(const SceneTables& sc) { return sc.use_grid ? 2 : (tables_in_lds(sc) ? 0 : 1); }
-int lds_share_limit(int bytes);
-int paths_lds_bytes(const SceneTables& sc, int mode);
-// SceneTables::scan_nodes_lds == -1 resolved: the nodes go to LDS when the scan form's workgroups per CU (LDS share) stay the same
-SceneTables resolve_scan_nodes(const SceneTables& sc) {
-  SceneTables t = sc;
-  if (t.scan_nodes_lds >= 0) return t;
-  SceneTables with = sc, without = sc;
-  with.scan_nodes_lds = 1, without.scan_nodes_lds = 0;
-  const int bw = paths_lds_bytes(with, 1), bo = paths_lds_bytes(without, 1);
-  t.scan_nodes_lds = (bw <= 64 * 1024 && lds_share_limit(bw) >= min(lds_share_limit(bo), PT_PATHS_SCAN_WAVES)) ? 1 : 0;  // (registers allow PT_PATHS_SCAN_WAVES workgroups per CU)
-  return t;
-}
-int paths_lds_bytes(const SceneTables& sc, int mode) {
-  const int rows = iter_hash_entries(sc) * 4 * max(0, sc.trace_depth - 1), common = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + rows;
-  const int top = sc.num_top * (int)sizeof(ptd::TopEntry);
-  switch (mode) {
-    case 0: return common + top + sc.num_geoms * (int)sizeof(ptd::Geom) + kWavesPerBlock * paths_wave_bytes<0>() + kMaxTop * 4 + 64 * 4;
-    case 1: return common + top + kWavesPerBlock * paths_wave_bytes<1>() + (sc.scan_nodes_lds > 0 ? sc.num_nodes * (int)sizeof(ptd::Node) : 0);
-    default: return common + kWavesPerBlock * paths_wave_bytes<2>();
-  }
-}
-int primary_grid_lds_bytes(const SceneTables& sc) {
-  return round16(sc.num_mats * (int)sizeof(ptd::Mat)) + kWavesPerBlock * grid_wave_bytes<kD0>() + iter_hash_entries(sc) * 4;
-}
-// The LDS-table kernel variants assume that every leaf is a top-list entry (no subtrees).
-bool leaves_fit_top(const SceneTables& sc) { return (sc.num_nodes + 1) / 2 <= kMaxTop; }
-// Stage the scene tables in LDS only if every leaf is a top-list entry and staging does not cost the dominant kernel
-// (k_paths) a resident block per CU against its form with the tables in memory.
-int lds_table_limit(const SceneTables& sc, int forced_bytes) {
-  if (forced_bytes >= 0) return leaves_fit_top(sc) ? forced_bytes : -1;
-  const int tbl = table_bytes(sc);
-  int with = 0, without = 0;
-  if (tbl <= kLdsTableBytes && leaves_fit_top(sc)) {
-    SceneTables in = sc;
-    in.lds_table_bytes = tbl;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with, k_paths<0>, kBlock, paths_lds_bytes(in, 0)) != hipSuccess) with = 0;
-  }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&without, k_paths<1>, kBlock, paths_lds_bytes(sc, 1)) != hipSuccess) without = 1;
-  (void)hipGetLastError();
-  return (with >= without && with > 0) ? tbl : -1;
-}
-
-// The occupancy query over-reports by one workgroup when the LDS of a block is a few hundred bytes under a 1/n share of the
-// CU's 160 KB (measured, round 4: 27,088 B per block: 6 reported, 5 resident — and a persistent grid one block too large runs
-// that block's whole share after everybody else: k_paths 1335 -> 1607 us).  A share is therefore counted in 1280-byte granules.
-#ifndef PT_LDS_GRANULE
-#define PT_LDS_GRANULE 1280
-#endif
-int lds_share_limit(int bytes) { return bytes > 0 ? (160 * 1024) / (((bytes + PT_LDS_GRANULE - 1) / PT_LDS_GRANULE) * PT_LDS_GRANULE) : 8; }
-int resident_blocks_per_cu(KernelId id, const SceneTables& sc) {
-  int n = 0, lds = 0;
-  hipError_t e = hipSuccess;
-  const int tbl = table_bytes(sc);
-  const bool in_lds = tables_in_lds(sc);
-  switch (id) {
-    case kGenerate:
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_generate, kBlock, 0);
-      break;
-    case kIntersect:
-      if (in_lds)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<true, false>, kBlock, round16(tbl) + kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
-      else
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect<false, false>, kBlock, kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry));
-      break;
-    case kIntersectLegacy:
-      if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<true, false>, kBlock, round16(tbl));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_intersect_legacy<false, false>, kBlock, 0);
-      break;
-    case kPrimary:
-      if (sc.use_grid) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false, true>, kBlock, lds = primary_grid_lds_bytes(sc));
-      else if (in_lds) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<true>, kBlock, lds = fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true));
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_primary<false>, kBlock, lds = fused_lds_bytes(sc, false, kWaveLds, true));
-      break;
-    case kPaths:
-      lds = paths_lds_bytes(resolve_scan_nodes(sc), paths_mode(sc));
-      if (paths_mode(sc) == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<0>, kBlock, lds);
-      else if (paths_mode(sc) == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<1>, kBlock, lds);
-      else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_paths<2>, kBlock, lds);
-      break;
-    case kShade:
-      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_shade, kBlock, round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4);
-      break;
-  }
-  if (e != hipSuccess || n < 1) n = 1;
-  n = min(n, max(1, lds_share_limit(lds)));
-  return n > 8 ? 8 : n;
-}
-
-void launch_generate(hipStream_t s, int grid, const ptd::Camera& cam, const BatchInfo& b, const ptd::Queues& qs,
-                     ptd::PathBuf out, int32_t* cnt0) {
-  hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, cam, b, qs, out, cnt0);
-}
-
-// exact_arith: the rays are primary rays (depth 0), traced with the reference's exact arithmetic in every mode
-void launch_intersect(hipStream_t s, int grid, const SceneTables& sc, const ptd::Queues& qs, const int32_t* cnt_in,
-                      ptd::PathBuf paths, ptd::HitBuf hits, bool legacy, bool exact_arith) {
-  const int bytes = table_bytes(sc);
-  const bool in_lds = tables_in_lds(sc);
-  const bool ex = kD0 && exact_arith;
-  const int wave_lds = kWavesPerBlock * kWaveLds + sc.num_top * (int)sizeof(ptd::TopEntry);
-  const int lds = legacy ? (in_lds ? round16(bytes) : 0) : (in_lds ? round16(bytes) : 0) + wave_lds;
-#define PT_LAUNCH_ISECT(K) hipLaunchKernelGGL(K, dim3(grid), dim3(kBlock), lds, s, sc, qs, cnt_in, paths, hits)
-  if (legacy) {
-    if (in_lds) { if (ex) PT_LAUNCH_ISECT((k_intersect_legacy<true, kD0>)); else PT_LAUNCH_ISECT((k_intersect_legacy<true, false>)); }
-    else { if (ex) PT_LAUNCH_ISECT((k_intersect_legacy<false, kD0>)); else PT_LAUNCH_ISECT((k_intersect_legacy<false, false>)); }
-  } else {
-    if (in_lds) { if (ex) PT_LAUNCH_ISECT((k_intersect<true, kD0>)); else PT_LAUNCH_ISECT((k_intersect<true, false>)); }
-    else { if (ex) PT_LAUNCH_ISECT((k_intersect<false, kD0>)); else PT_LAUNCH_ISECT((k_intersect<false, false>)); }
-  }
-#undef PT_LAUNCH_ISECT
-}
-
-void launch_primary(hipStream_t s, int grid, const SceneTables& sc, const ptd::Camera& cam, const BatchInfo& b,
-                    const ptd::Queues& qs, int32_t* cnt0, int32_t* cnt_out, ptd::PathBuf out, ptd::RetireBuf ret) {
-  if (sc.use_grid) hipLaunchKernelGGL((k_primary<false, true>), dim3(grid), dim3(kBlock), primary_grid_lds_bytes(sc), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
-  else if (tables_in_lds(sc)) hipLaunchKernelGGL(k_primary<true>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, true, primary_ring<true, false>() ? carry_bytes<true>() : kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
-  else hipLaunchKernelGGL(k_primary<false>, dim3(grid), dim3(kBlock), fused_lds_bytes(sc, false, kWaveLds, true), s, sc, cam, b, qs, cnt0, cnt_out, out, ret);
-}
-
-void launch_paths(hipStream_t s, int grid, const SceneTables& sc_in, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret) {
-  const SceneTables sc = resolve_scan_nodes(sc_in);
-  const int bytes = paths_lds_bytes(sc, paths_mode(sc));
-  if (paths_mode(sc) == 0) hipLaunchKernelGGL(k_paths<0>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
-  else if (paths_mode(sc) == 1) hipLaunchKernelGGL(k_paths<1>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
-  else hipLaunchKernelGGL(k_paths<2>, dim3(grid), dim3(kBlock), bytes, s, sc, b, qs, cnt, in, ret);
-}
-void launch_shade(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, int depth, const ptd::Queues& qs,
-                  const int32_t* cnt_in, int32_t* cnt_out, ptd::PathBuf in, ptd::HitBuf hits, ptd::PathBuf out,
-                  ptd::RetireBuf ret) {
-  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat)) + iter_hash_entries(sc) * 4;
-  hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), bytes, s, sc, b, depth, qs, cnt_in, cnt_out, in, hits, out,
-                     ret);
-}
-
-int flat_grid(int n, int cap) {
-  int grid = (n + kBlock - 1) / kBlock;
-  return grid > cap ? cap : (grid < 1 ? 1 : grid);
-}
-void launch_collect(hipStream_t s, const BatchInfo& b, const ptd::Queues& qs, ptd::RetireBuf ret, float* image_rgb) {
-  // 96 KB of dynamic LDS: above the 64 KB a kernel gets without asking (per device: set on every launch, it is cheap)
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collect), hipFuncAttributeMaxDynamicSharedMemorySize, collect_lds_bytes());
-  hipLaunchKernelGGL(k_collect, dim3(qs.Q), dim3(kCollectThreads), collect_lds_bytes(), s, b, qs, ret, image_rgb);
-}
-
-// Device self-check of the guarded IEEE sequences (namespace ieee) against the compiler's own expansions — pt_selfcheck_ieee.
-// kind 0 sqrt, 1 reciprocal, 2 1/sqrt: operand = the bit pattern first + i (a wave holds 64 consecutive patterns, so whole waves
-// are inside or outside the guarded range and both paths get exercised); kind 3 a / b, 4 the shared-reciprocal forms (div2, div3,
-// rcp3): operands from a hash of (seed, i), exponents drawn per WAVE either inside the guarded range (every lane: the short
-// sequence runs) or over everything incl. zeros, denormals, infinities and NaNs (the expansion runs), mantissas and signs per lane.
-PT_DEV bool same_float(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
-PT_DEV uint32_t mix32(uint32_t x) {
-  x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
-  return x;
-}
-__global__ void k_ieee_check(int kind, unsigned long long first, unsigned long long count, uint32_t seed, unsigned long long* __restrict__ bad) {
-#pragma clang fp contract(off)
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  unsigned long long mism = 0;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const unsigned long long n = first + i;
-    if (kind <= 2) {
-      const float x = __uint_as_float((uint32_t)n);
-      const float got = kind == 0 ? ieee::sqrt(x) : kind == 1 ? ieee::rcp(x) : ieee::rcp_sqrt(x);
-      const float want = kind == 0 ? __builtin_sqrtf(x) : kind == 1 ? 1.0f / x : 1.0f / __builtin_sqrtf(x);
-      mism += !same_float(got, want);
-    } else {
-      const uint32_t wave_key = mix32((uint32_t)(n >> 6) ^ seed);
-      const bool inside = (wave_key & 7u) != 0u;  // 7 of 8 waves: every operand inside the guarded range
-      float v[4];
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t h = mix32((uint32_t)n * 4u + (uint32_t)j + mix32(seed + (uint32_t)(n >> 30)));
-        uint32_t e = inside ? 80u + (mix32(h ^ 0x9e3779b9u) % 94u) : (h >> 23) & 255u;   // biased exponent: [2^-47, 2^47) or anything
-        if (inside && (h & 0x1fu) == 0u) e = (h & 0x20u) ? 80u : 173u;                   // the edges of the range more often
-        v[j] = __uint_as_float((h & 0x807fffffu) | (e << 23));
-        if (!inside && (h & 0x300u) == 0u) v[j] = __uint_as_float(h & 0x80000000u);      // zeros among the unrestricted operands
-      }
-      if (kind == 3) {
-        mism += !same_float(ieee::div(v[0], v[1]), v[0] / v[1]);
-      } else {
-        float q1, q2, x = v[0], y = v[1], z = v[2], rx, ry, rz;
-        ieee::div2(v[0], v[1], v[3], q1, q2);
-        mism += !same_float(q1, v[0] / v[3]) + !same_float(q2, v[1] / v[3]);
-        if (n & 64u) x = __uint_as_float(__float_as_uint(x) & 0x80000000u);  // a signed zero numerator sends the wave through the expansion
-        const float x0 = x;
-        ieee::div3(x, y, z, v[3]);
-        mism += !same_float(x, x0 / v[3]) + !same_float(y, v[1] / v[3]) + !same_float(z, v[2] / v[3]);
-        ieee::rcp3(v[0], v[1], v[2], rx, ry, rz);
-        mism += !same_float(rx, 1.0f / v[0]) + !same_float(ry, 1.0f / v[1]) + !same_float(rz, 1.0f / v[2]);
-      }
-    }
-  }
-  if (mism) atomicAdd(bad, mism);
-}
-void launch_ieee_check(hipStream_t s, int kind, unsigned long long first, unsigned long long count, uint32_t seed, unsigned long long* bad) {
-  hipLaunchKernelGGL(k_ieee_check, dim3(4096), dim3(kBlock), 0, s, kind, first, count, seed, bad);
-}
-
-void launch_count_stats(hipStream_t s, const ptd::Queues& qs, int32_t* cnt, int depth_count,
-                        unsigned long long* stats) {
-  hipLaunchKernelGGL(k_count_stats, dim3(depth_count + 1), dim3(kBlock), 0, s, qs, cnt, depth_count, stats);
-}
-
-void launch_preview(hipStream_t s, int n, int iterations, const float* image_rgb, uchar4* rgba) {
-  hipLaunchKernelGGL(k_preview, dim3(flat_grid(n, 4096)), dim3(kBlock), 0, s, n, iterations, image_rgb, rgba);
-}
-
-void launch_save_u8(hipStream_t s, int n, int width, float samples, const float* image_rgb, uint8_t* rgb8) {
-  hipLaunchKernelGGL(k_save_u8, dim3(flat_grid(n, 4096)), dim3(kBlock), 0, s, n, width, samples, image_rgb, rgb8);
-}
-
-void launch_shade_stage(hipStream_t s, const SceneTables& sc, int trace_depth, int depth, int n, const int32_t* iter,
-                        const int32_t* pixel, ptd::HitBuf hits, ptd::PathBuf paths, int32_t* alive) {
-  const int bytes = round16(sc.num_mats * (int)sizeof(ptd::Mat));
-  hipLaunchKernelGGL(k_shade_stage, dim3(flat_grid(n, 2048)), dim3(kBlock), bytes, s, sc, trace_depth, depth, n, iter, pixel, hits,
-                     paths, alive);
-}
-
+#include "pt_output.inc"
+#include "pt_launch.inc"
 const KernelApi kApi = {
 #if PT_ARITH == 0
     "exact",

@@ -2,7 +2,7 @@
 # Builds an A/B variant of the whole library (all three kernel translation units with extra -D flags) into
 # build/variants/NAME.so; load it with PT_AMD_LIB=build/variants/NAME.so (capi.py).  The in-tree library is untouched.
 # usage: tools/build_variant.sh NAME "-DPT_BOUNCE_WAVES=4 ..." [GIT_REV]
-# With GIT_REV the kernel sources (pt_kernels.hip, pt_arith.inc, headers) are taken from that commit instead of the
+# With GIT_REV the kernel sources (pt_kernels.hip, its *.inc files, headers) are taken from that commit instead of the
 # working tree (old-vs-new A/B in one gpurun call); the host objects are the current ones, so the C ABI must match.
 set -e
 NAME=$1; FLAGS=$2; REV=${3:-}
@@ -12,8 +12,9 @@ KSRC=$SRC
 if [ -n "$REV" ]; then
   KSRC=$ROOT/build/variants/src_$NAME
   mkdir -p $KSRC
-  for f in pt_kernels.hip pt_arith.inc pt_kernels.h pt_device.h pt_portable_math.h; do
-    git -C $ROOT show $REV:cosc_4397_pathtracing_raytracing_project_amd/csrc/$f > $KSRC/$f
+  rm -f $KSRC/*
+  for f in $(git -C $ROOT ls-tree --name-only $REV cosc_4397_pathtracing_raytracing_project_amd/csrc/ | grep -E '\.(hip|inc|h)$'); do  # the revision's own kernel sources
+    git -C $ROOT show $REV:$f > $KSRC/$(basename $f)
   done
 fi
 OUT=$ROOT/build/variants

@@ -20,7 +20,7 @@ body = m.group(2)
 files = {int(f.group(1)): (f.group(3) or f.group(2)).split("/")[-1] for f in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s)}
 # function start lines of the two sources
 funcs = {}
-for fn in ("pt_kernels.hip", "pt_arith.inc"):
+for fn in ("pt_kernels.hip", "pt_arith.inc", "pt_ieee.inc", "pt_shade.inc", "pt_grid.inc", "pt_output.inc", "pt_launch.inc", "pt_ieee_check.inc"):
     starts = []
     for i, l in enumerate(open(os.path.join(SRC, fn)).read().splitlines(), 1):
         mm = re.match(r"^(?:template.*?>\s*)?(?:PT_DEV|__global__|__host__ __device__ inline|static PT_DEV|inline)\b.*?\b(\w+)\s*\(", l)
