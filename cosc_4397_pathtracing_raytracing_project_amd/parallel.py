@@ -51,10 +51,13 @@ def striped_rows(height: int, rank: int, world: int) -> List[int]:
     return list(range(rank, height, world))
 
 
-def gather_tiles(tile, width: int, height: int, rank: int, world: int, dst: int = 0, striped: bool = False):
+def gather_tiles(tile, width: int, height: int, rank: int, world: int, dst: int = 0, striped: bool = False,
+                 always_collective: bool = False):
     """Collect per-rank tiles ([count, 3] float32 tensors, on the GPU for nccl) on rank `dst`
-    and return the assembled [H*W, 3] image there (None elsewhere).  One collective."""
-    if world == 1:
+    and return the assembled [H*W, 3] image there (None elsewhere).  One collective.
+    `always_collective`: go through the process group even for one rank (tests: the nccl = RCCL
+    gather on a one-GPU box)."""
+    if world == 1 and not always_collective:
         return tile
     import torch
     import torch.distributed as dist

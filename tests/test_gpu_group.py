@@ -268,3 +268,28 @@ def test_bench_two_ranks_rehearsal_on_one_card(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 12 and d["value"] > 0 and d["scaling"] == "strong"
     assert "interleaved-row tiles" in d["config"]["workload"] and d["config"]["arith"] == "fast"
     assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+def test_gather_tiles_through_rccl_with_one_rank(tmp_path):
+    """What a one-GPU box can run of the nccl (= RCCL) write-out: a one-rank process group on the card, the tile gather of
+    parallel.gather_tiles through it (communicator creation, the collective call with device tensors, row placement of a
+    striped tile).  More than one rank needs more than one GPU (RCCL refuses two ranks on one device): NOT RUN here."""
+    import sys
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from cosc_4397_pathtracing_raytracing_project_amd import parallel\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29519', world_size=1, rank=0, device_id=torch.device('cuda', 0))\n"
+        "W, H = 64, 6\n"
+        "tile = torch.arange(W * H * 3, dtype=torch.float32, device='cuda:0').view(W * H, 3)\n"
+        "for striped in (False, True):\n"
+        "    full = parallel.gather_tiles(tile, W, H, 0, 1, striped=striped, always_collective=True)\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert full.is_cuda and torch.equal(full, tile), striped\n"
+        "print('backend', dist.get_backend())\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "backend nccl" in p.stdout
