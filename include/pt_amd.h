@@ -178,7 +178,7 @@ int pt_build_bvh(const PtGeom* geoms, int num_geoms, PtBVHNode* out, int cap);
  * BVH of pathtrace.cu:52-111): a uniform grid over the leaf boxes, walked by the depth-0 and depth >= 1 kernels instead of
  * the BVH.  The image is the same either way: a primitive is tested exactly when the ray passes the primitive's own box
  * test, and every leaf is listed in all cells its box, grown by `pad`, touches.  A scene is a CANDIDATE when it has
- * >= 1024 BVH nodes and its lists stay moderate (at most 64 cell references per primitive; `forced` skips both
+ * >= 600 BVH nodes and its lists stay moderate (at most 64 cell references per primitive; `forced` skips both
  * conditions, as PtOptions.debug_flags 256 does); for a candidate pt_init / pt_ctx_create time a few iterations of the
  * tile with the BVH scan, with this grid and with two finer ones (4 and 8 cells per primitive) and keep the fastest
  * (PtStats.grid_cells > 0: a grid, with that many cells).  The device walks the same structure over the boxes of
@@ -203,7 +203,7 @@ int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* in
  * what sphereIntersectionTest's float arithmetic, intersections.h:102-144, can still report as a hit for ray origins inside
  * the scene bounds or at `camera_position`; csrc/pt_api.cpp sphere_tight_box).  A ray that passes the tightened box passes the
  * reference's; a ray that passes only the reference's misses the sphere: same hits, fewer candidates.  boxes[g] = {min xyz, max xyz}.
- * Returns the number of tightened leaves (pt_init applies it from 1024 BVH nodes on; PtOptions.debug_flags 2048 turns it off). */
+ * Returns the number of tightened leaves (pt_init applies it from 64 BVH nodes on; PtOptions.debug_flags 2048 turns it off). */
 int pt_traversal_boxes(const PtGeom* geoms, int num_geoms, const float camera_position[3], float* boxes);
 
 /* transform / inverse / inverse-transpose of an OBJECT block's TRANS ROTAT SCALE
