@@ -44,10 +44,6 @@ class PtBVHNode(C.Structure):
                 ("geomIndex", C.c_int32)]
 
 
-class PtWideInfo(C.Structure):
-    _fields_ = [("num_nodes", C.c_int32), ("num_leaves", C.c_int32), ("max_stack", C.c_int32), ("reserved", C.c_int32)]
-
-
 class PtGridInfo(C.Structure):
     _fields_ = [("res", C.c_int32 * 3), ("origin", C.c_float * 3), ("cell_size", C.c_float * 3), ("pad", C.c_float),
                 ("num_cells", C.c_int32), ("num_records", C.c_int32), ("num_leaves", C.c_int32)]
@@ -74,7 +70,7 @@ class PtStats(C.Structure):
                 ("intersect_ms", C.c_double), ("render_ms", C.c_double), ("num_cus", C.c_int32),
                 ("grid_blocks", C.c_int32), ("num_queues", C.c_int32), ("iters_per_batch", C.c_int32),
                 ("device_bytes", C.c_int64), ("primary_fused", C.c_int32), ("bounces_fused", C.c_int32),
-                ("arith", C.c_int32), ("grid_cells", C.c_int32), ("tight_leaves", C.c_int32), ("wide_nodes", C.c_int32)]
+                ("arith", C.c_int32), ("grid_cells", C.c_int32), ("tight_leaves", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class PtError(RuntimeError):
@@ -105,8 +101,6 @@ def lib() -> C.CDLL:
     L.pt_scene_image_name.restype = C.c_char_p
     L.pt_build_bvh.argtypes = [C.POINTER(PtGeom), C.c_int, C.POINTER(PtBVHNode), C.c_int]
     L.pt_build_grid.argtypes = [C.POINTER(PtGeom), C.c_int, C.c_int, C.POINTER(PtGridInfo), C.POINTER(C.c_uint32), C.POINTER(PtGridRecord)]
-    if hasattr(L, "pt_build_wide"):
-        L.pt_build_wide.argtypes = [C.POINTER(PtGeom), C.c_int, C.c_int, _fp, C.POINTER(PtWideInfo), _fp, C.c_int]
     if hasattr(L, "pt_selfcheck_ieee"):
         L.pt_selfcheck_ieee.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
     if hasattr(L, "pt_traversal_boxes"):  # absent from older A/B builds of the library (tools/build_rev.sh)
@@ -228,20 +222,6 @@ class Scene:
         recs = (PtGridRecord * info.num_records)()
         lib().pt_build_grid(self.desc.geoms, self.desc.num_geoms, int(forced), C.byref(info), start, recs)
         return info, np.frombuffer(start, np.uint32).copy(), recs
-
-    def wide_tree(self, tighten: bool = False):
-        """The 4-wide surface-area tree depths >= 1 walk on scenes of more than 32 primitives (pt_build_wide): (info, boxes
-        [nodes, 6, 4] child-major planes bmin.xyz, bmax.xyz, links [nodes, 4] int32)."""
-        info = PtWideInfo()
-        cam = np.asarray(list(self.desc.camera.position), np.float32)
-        n = lib().pt_build_wide(self.desc.geoms, self.desc.num_geoms, int(tighten), _f(cam), C.byref(info), None, 0)
-        if n < 0:
-            raise PtError(lib().pt_last_error().decode(errors="replace"))
-        words = np.zeros((max(n, 1), 28), np.float32)
-        if n > 0:
-            lib().pt_build_wide(self.desc.geoms, self.desc.num_geoms, int(tighten), _f(cam), C.byref(info), _f(words), n)
-        words = words[:n]
-        return info, words[:, :24].reshape(n, 6, 4).copy(), words[:, 24:].copy().view(np.int32)
 
     def traversal_boxes(self):
         """(boxes [num_geoms, 6], tightened count): the leaf boxes the traversal structures of a LARGE scene test

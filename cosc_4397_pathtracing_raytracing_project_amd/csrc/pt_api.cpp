@@ -15,7 +15,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <functional>
 #include <string>
 #include <vector>
 
@@ -35,7 +34,6 @@ constexpr bool kAblateBuild = false;  // release library: pt_init rejects them
 
 std::string g_err;
 constexpr int kGridNodes = 600;        // scenes from this many BVH nodes on are candidates for the uniform grid (build_grid, choose_traversal); the ladder scene of 500 primitives (999 nodes): scan 3.9 k, grid 4.7 k Msamples/s, 156 primitives (311 nodes): 5.5 / 5.3
-constexpr int kWideStackMax = 48;      // deepest per-lane stack (16-bit entries in LDS) the wide-tree walk is launched with; a tree that needs more is not used
 constexpr int kTightNodes = 64;        // scenes from this many BVH nodes on test sphere leaves against the ellipsoid's box (sphere_tight_box); the
                                        // reference's own scenes (cornell.txt: 13 nodes) keep the reference's boxes
 }  // namespace
@@ -114,10 +112,6 @@ struct PtContext {
     size_t bytes;
   };
   std::vector<GridAlt> grid_alts;
-  // 4-wide BVH over the leaf boxes (build_wide; SceneTables::wide), scenes whose leaves do not fit the LDS-table form
-  ptd::Word4* d_wide = nullptr;
-  int num_wide = 0, wide_stack = 0;
-  bool have_wide = false;
   int tight_leaves = 0;  // sphere leaves with a tightened traversal box (tighten_sphere_leaves)
   bool grid_enabled = true;      // the outcome of choose_traversal()
   float probe_ms[2] = {0.f, 0.f};  // a few iterations with the BVH scan / with the (fastest) grid, as timed by choose_traversal()
@@ -521,154 +515,6 @@ bool build_grid(const std::vector<ptd::Node>& nodes, const std::vector<PtGeom>& 
   return true;
 }
 
-// 4-wide BVH over the leaf boxes — the traversal structure of our own for scenes between the LDS-table form (every leaf tested
-// directly, <= 32 leaves) and the uniform grid (SceneTables::wide; walked per lane by k_paths mode 3, pt_wide.inc).  The
-// reference's tree is a median split along the longest axis (pathtrace.cu:52-111) and has to be visited in ITS order by the
-// stackless scan (19 dependent node fetches per ray at 156 primitives after 32 top-list tests); here the
-// binary tree is built with the surface-area heuristic (full sweep over the three axes: scenes of this class have at most a
-// few thousand primitives) and collapsed to four children per node by repeatedly opening the child with the largest surface.
-// Results cannot change: a leaf's child record carries the leaf's own box, bit for bit, and inner boxes are exact unions
-// (min / max of floats), so the walk delivers every leaf whose own box test passes; the key (t, threaded leaf index) picks the
-// reference's winner among them.
-struct WideBuild {
-  std::vector<ptd::Word4> words;  // ptd::kWideWords per node (pt_device.h), node 0 = root
-  int max_stack = 0;            // most entries a lane's stack can hold during a walk of this tree
-};
-bool build_wide(const std::vector<ptd::Node>& nodes, const std::vector<PtGeom>& geoms, WideBuild& wb) {
-  struct Item {
-    float lo[3], hi[3];
-    int leaf;
-  };
-  std::vector<Item> items;
-  for (size_t i = 0; i < nodes.size(); ++i)
-    if (nodes[i].geom >= 0) {
-      Item it;
-      std::memcpy(it.lo, nodes[i].bmin, 12), std::memcpy(it.hi, nodes[i].bmax, 12);
-      it.leaf = (int)i;
-      for (int a = 0; a < 3; ++a)
-        if (!std::isfinite(it.lo[a]) || !std::isfinite(it.hi[a])) return false;
-      items.push_back(it);
-    }
-  if (items.empty() || geoms.size() > ((size_t)1 << ptd::kWideGeomBits) || nodes.size() > ((size_t)1 << ptd::kWideLeafBits)) return false;  // the leaf links' bit fields
-  struct BNode {
-    float lo[3], hi[3];
-    int left, right;  // < 0: leaf, items[~left]
-  };
-  std::vector<BNode> bn;
-  auto area = [](const float lo[3], const float hi[3]) {
-    const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
-    return 2.0 * (dx * dy + dy * dz + dz * dx);
-  };
-  // binary SAH tree over items[first, first + n); returns the node index, or ~item for a single item
-  std::function<int(int, int)> build = [&](int first, int n) -> int {
-    if (n == 1) return ~first;
-    int best_axis = -1, best_split = 0;
-    double best_cost = INFINITY;
-    std::vector<double> right_area((size_t)n);
-    for (int axis = 0; axis < 3; ++axis) {
-      std::sort(items.begin() + first, items.begin() + first + n, [axis](const Item& a, const Item& b) {
-        const float ca = a.lo[axis] + a.hi[axis], cb = b.lo[axis] + b.hi[axis];
-        return ca != cb ? ca < cb : a.leaf < b.leaf;
-      });
-      float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-      for (int i = n - 1; i > 0; --i) {
-        for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], items[first + i].lo[a]), hi[a] = std::max(hi[a], items[first + i].hi[a]);
-        right_area[i] = area(lo, hi);
-      }
-      for (int a = 0; a < 3; ++a) lo[a] = INFINITY, hi[a] = -INFINITY;
-      for (int i = 1; i < n; ++i) {  // left = [0, i), right = [i, n)
-        for (int a = 0; a < 3; ++a) lo[a] = std::min(lo[a], items[first + i - 1].lo[a]), hi[a] = std::max(hi[a], items[first + i - 1].hi[a]);
-        const double cost = area(lo, hi) * i + right_area[i] * (n - i);
-        if (cost < best_cost) best_cost = cost, best_axis = axis, best_split = i;
-      }
-    }
-    if (best_axis != 2)
-      std::sort(items.begin() + first, items.begin() + first + n, [best_axis](const Item& a, const Item& b) {
-        const float ca = a.lo[best_axis] + a.hi[best_axis], cb = b.lo[best_axis] + b.hi[best_axis];
-        return ca != cb ? ca < cb : a.leaf < b.leaf;
-      });
-    const int self = (int)bn.size();
-    bn.push_back(BNode{});
-    const int l = build(first, best_split), r = build(first + best_split, n - best_split);
-    BNode& b = bn[self];
-    b.left = l, b.right = r;
-    for (int a = 0; a < 3; ++a) b.lo[a] = INFINITY, b.hi[a] = -INFINITY;
-    for (int c : {l, r}) {
-      const float* clo = c < 0 ? items[~c].lo : bn[c].lo;
-      const float* chi = c < 0 ? items[~c].hi : bn[c].hi;
-      for (int a = 0; a < 3; ++a) b.lo[a] = std::min(b.lo[a], clo[a]), b.hi[a] = std::max(b.hi[a], chi[a]);
-    }
-    return self;
-  };
-  const int root = build(0, (int)items.size());
-  // collapse: a wide node's children = the binary node's two, the largest inner one opened until there are four
-  struct Pending {
-    int bnode, wide;
-  };
-  std::vector<Pending> todo;
-  int num_wide = 0;
-  auto set_child = [&](int w, int j, const float lo[3], const float hi[3], int32_t link) {
-    float* p = reinterpret_cast<float*>(&wb.words[(size_t)w * ptd::kWideWords]);
-    for (int a = 0; a < 3; ++a) p[4 * a + j] = lo[a], p[4 * (3 + a) + j] = hi[a];
-    std::memcpy(&p[4 * 6 + j], &link, 4);
-  };
-  auto new_wide = [&](int bnode) {
-    const int w = num_wide++;
-    wb.words.resize((size_t)num_wide * ptd::kWideWords, ptd::Word4{0.f, 0.f, 0.f, 0.f});  // all links 0: no child
-    todo.push_back(Pending{bnode, w});
-    return w;
-  };
-  auto leaf_link = [&](const Item& it) {
-    const int gi = nodes[it.leaf].geom;
-    return (int32_t)(0x80000000u | ((uint32_t)(geoms[gi].type & 3) << 29) | ((uint32_t)gi << ptd::kWideLeafBits) | (uint32_t)it.leaf);
-  };
-  std::vector<std::vector<int>> kids;  // inner children (wide indices) per wide node, for the stack bound
-  if (root < 0) {  // a single primitive: a root with one leaf child
-    num_wide = 1;
-    wb.words.resize(ptd::kWideWords, ptd::Word4{0.f, 0.f, 0.f, 0.f});
-    const Item& it = items[~root];
-    set_child(0, 0, it.lo, it.hi, leaf_link(it));
-  } else {
-    new_wide(root);
-  }
-  for (size_t t = 0; t < todo.size(); ++t) {
-    const Pending pd = todo[t];
-    std::vector<int> ch{bn[pd.bnode].left, bn[pd.bnode].right};
-    while (ch.size() < 4) {
-      int open = -1;
-      double amax = -1.0;
-      for (size_t i = 0; i < ch.size(); ++i)
-        if (ch[i] >= 0 && area(bn[ch[i]].lo, bn[ch[i]].hi) > amax) amax = area(bn[ch[i]].lo, bn[ch[i]].hi), open = (int)i;
-      if (open < 0) break;
-      const int c = ch[open];
-      ch[open] = bn[c].left;
-      ch.push_back(bn[c].right);
-    }
-    if (kids.size() <= (size_t)pd.wide) kids.resize(pd.wide + 1);
-    for (size_t j = 0; j < ch.size(); ++j) {
-      if (ch[j] < 0) {
-        const Item& it = items[~ch[j]];
-        set_child(pd.wide, (int)j, it.lo, it.hi, leaf_link(it));
-      } else {
-        const int w = new_wide(ch[j]);
-        set_child(pd.wide, (int)j, bn[ch[j]].lo, bn[ch[j]].hi, w);
-        kids[pd.wide].push_back(w);
-      }
-    }
-  }
-  if (num_wide > 65535) return false;  // the lanes' stacks hold 16-bit node indices
-  kids.resize(num_wide);
-  // stack bound: at a node with m inner children up to m - 1 wait while one of them is walked
-  std::vector<int> need(kids.size(), 0);
-  for (int w = (int)kids.size() - 1; w >= 0; --w) {  // children have larger indices than their parent
-    int deepest = 0;
-    for (int c : kids[w]) deepest = std::max(deepest, need[c]);
-    need[w] = kids[w].empty() ? 0 : (int)kids[w].size() - 1 + deepest;
-  }
-  wb.max_stack = std::max(1, need[0]);
-  return true;
-}
-
 ptk::SceneTables tables(const Ctx& g) {
   ptk::SceneTables t{};
   t.nodes = g.d_nodes;
@@ -690,13 +536,6 @@ ptk::SceneTables tables(const Ctx& g) {
   {
     const char* e = getenv("PT_SCAN_NODES_LDS");  // experiment knob: 0 / 1 = never / always; default: when it costs k_paths no resident workgroup
     t.scan_nodes_lds = e ? (atoi(e) ? 1 : 0) : -1;
-  }
-  t.wide = g.d_wide, t.num_wide = g.num_wide, t.wide_stack = g.wide_stack;
-  t.use_wide = g.have_wide ? 1 : 0;
-  if (g.have_wide && (g.debug_flags & 1024)) t.lds_table_bytes = -1;  // (a forced wide tree on a small scene: its kernels read the tables from memory)
-  {
-    const char* e = getenv("PT_WIDE_NODES_LDS");  // experiment knob like PT_SCAN_NODES_LDS
-    t.wide_lds = e ? (atoi(e) ? 1 : 0) : -1;
   }
   // debug_flags 256 builds and uses the grid for any scene, 512 never (A/B, same results)
   t.use_grid = g.have_grid && g.grid_enabled && !(g.debug_flags & 512) ? 1 : 0;
@@ -1093,17 +932,6 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
-  // the wide tree: debug_flags 1024 builds and walks it for any scene that is not rendered from LDS tables, 4096 never
-  if (((g.num_nodes + 1) / 2 > ptk::kMaxTop || (g.debug_flags & 1024)) && !(g.debug_flags & 4096)) {
-    WideBuild wb;
-    if (build_wide(nodes, g.geoms, wb) && wb.max_stack <= kWideStackMax) {
-      if (dalloc(g, &g.d_wide, wb.words.size())) return -1;
-      HIP_OK(hipMemcpy(g.d_wide, wb.words.data(), wb.words.size() * sizeof(ptd::Word4), hipMemcpyHostToDevice));
-      g.num_wide = (int)(wb.words.size() / ptd::kWideWords);
-      g.wide_stack = (wb.max_stack + 1) & ~1;
-      g.have_wide = true;
-    }
-  }
   if ((g.num_nodes >= kGridNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
     const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive instead of the search
     double cam_mag = 0.0;
@@ -1273,29 +1101,6 @@ int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* in
   return 1;
 }
 
-int pt_build_wide(const PtGeom* geoms, int num_geoms, int tighten, const float camera_position[3], PtWideInfo* info, float* out, int cap_nodes) {
-  if (!geoms || num_geoms <= 0 || !info || (tighten && !camera_position)) return fail("pt_build_wide: null argument");
-  std::vector<PtBVHNode> ref_nodes;
-  pt::buildBVH(geoms, num_geoms, ref_nodes);
-  std::vector<ptd::Node> nodes;
-  std::vector<int> where(ref_nodes.size(), -1);
-  thread_bvh(ref_nodes, 0, nodes, where);
-  const std::vector<PtGeom> gv(geoms, geoms + num_geoms);
-  if (tighten) {
-    double olo[3], ohi[3];
-    origin_region(ref_nodes[0].bmin, ref_nodes[0].bmax, camera_position, olo, ohi);
-    (void)tighten_sphere_leaves(nodes, gv, olo, ohi);
-  }
-  std::memset(info, 0, sizeof(*info));
-  info->num_leaves = num_geoms;
-  WideBuild wb;
-  if (!build_wide(nodes, gv, wb)) return 0;
-  info->num_nodes = (int32_t)(wb.words.size() / ptd::kWideWords);
-  info->max_stack = wb.max_stack;
-  if (out) std::memcpy(out, wb.words.data(), (size_t)std::min(cap_nodes, info->num_nodes) * ptd::kWideWords * sizeof(ptd::Word4));
-  return info->num_nodes;
-}
-
 int pt_build_transform(const float* trs, float* transform, float* inverse, float* invTranspose) {
   if (!trs || !transform || !inverse || !invTranspose) return fail("pt_build_transform: null argument");
   pt::buildTransform(trs, transform, inverse, invTranspose);
@@ -1452,10 +1257,7 @@ int pt_ctx_get_stats(PtContext* c, PtStats* out) {
   out->arith = g.arith;
   out->grid_cells = (tables(g).use_grid && g.fuse_bounces) ? g.grid_res[0] * g.grid_res[1] * g.grid_res[2] : 0;
   out->tight_leaves = g.tight_leaves;
-  {
-    const ptk::SceneTables t = tables(g);
-    out->wide_nodes = (g.fuse_bounces && g.depth > 1 && t.use_wide && !t.use_grid && t.lds_table_bytes < 0) ? g.num_wide : 0;
-  }
+  out->reserved0 = 0;
   return 0;
 }
 

@@ -38,16 +38,6 @@ struct TopEntry {
 };
 static_assert(sizeof(TopEntry) == 32, "TopEntry must be 32 B");
 
-// Node of the 4-wide tree of our own (pt_api.cpp build_wide, pt_wide.inc): 7 words of 16 bytes, child-major inside a word —
-// bmin.x[4], bmin.y[4], bmin.z[4], bmax.x[4], bmax.y[4], bmax.z[4], link[4].  link > 0: index of an inner node (the root is
-// node 0 and nobody's child); 0: no child; bit 31 set: a leaf — threaded node index (the first-found order key) in bits 0-14,
-// geom index in bits 15-28, primitive type in bits 29-30.  An ODD number of 16-byte words on purpose: the lanes of a wave read
-// the same word of DIFFERENT nodes with ds_read_b128, whose banking is by 16-byte slot of a 256-byte row — a 128-byte node
-// would put every lane on one of two slots (8-way conflicts, measured: a walk step cost 1000 SIMD cycles), 7 words spread the
-// nodes over all 16.
-constexpr int kWideWords = 7;
-constexpr int kWideLeafBits = 15, kWideGeomBits = 14;
-
 // Geometry record, 272 B.  Only rows 0..2 of each matrix are ever used
 // (multiplyMV returns vec3, src/intersections.h:34-36), stored m[c*3+r] == glm m[c][r].
 struct Geom {

@@ -52,13 +52,6 @@ struct SceneTables {
   int32_t use_grid;
   int32_t trace_depth;    // of the context (k_paths sizes its iteration-hash rows with it)
   int32_t has_triangles;  // mesh extension: some geoms are PT_GEOM_TRIANGLE (the sphere-only chunk specialisation is off)
-  // 4-wide BVH of our own over the (traversal) leaf boxes, built by the host with the surface-area heuristic (pt_api.cpp
-  // build_wide; walked per lane by k_paths mode 3, pt_wide.inc): node i = the ptd::kWideWords 16-byte words from wide[7 i] on (pt_device.h).
-  const ptd::Word4* wide;
-  int32_t num_wide;    // nodes
-  int32_t wide_stack;  // entries of a lane's stack the walk can need in this tree (the host's bound)
-  int32_t use_wide;    // 1: k_paths walks it (mid-size scenes: too many leaves for the LDS-table form)
-  int32_t wide_lds;    // 1 = the nodes are staged in LDS, 0 = read from memory, -1 = staged when that costs no resident workgroup per CU (resolved at launch)
   int32_t scan_nodes_lds;  // k_paths mode 1: 1 = the threaded nodes are staged in LDS for the subtree scans (scenes of a few hundred nodes:
                            // 64 primitives +4 % Msamples/s), 0 = read from memory, -1 = staged when that costs no resident workgroup per CU (resolved at launch)
 };

@@ -1094,7 +1094,6 @@ PT_DEV void carry_drain_to(Carry<SMALL, NPAR>& c, int mark, int lane, const ptd:
 }
 
 #include "pt_grid.inc"
-#include "pt_wide.inc"
 // ── depth 0 fused: generateRayFromCamera + computeIntersections + shadeAndExtendRays ────────
 // Primary rays are a pure function of the sample id, so depth 0 needs no path state in memory at
 // all: the ray is built in registers, traced with the same wave-cooperative search, shaded, and
@@ -1480,15 +1479,15 @@ constexpr bool paths_slots_in_lds() { return MODE == 0 || (MODE == 1 && PT_SLOTS
 template <int MODE>
 constexpr int paths_extra_bytes() { return (paths_slots_in_lds<MODE>() ? kSlotBytes : 0) + 512; }  // refill slots + 64 counters: paths retired per depth + 64: record slots per sub-list
 template <int MODE>
-constexpr int paths_wave_bytes() {  // MODE 3: + SceneTables::wide_stack * 128 (the lanes' stacks, sized for the tree at hand)
-  return (MODE == 0 ? kLanesBytes : MODE == 1 ? carry_bytes<false, 1>() : MODE == 2 ? grid_wave_bytes<false>() : kWideCoreBytes) + paths_extra_bytes<MODE>();
+constexpr int paths_wave_bytes() {
+  return (MODE == 0 ? kLanesBytes : MODE == 1 ? carry_bytes<false, 1>() : grid_wave_bytes<false>()) + paths_extra_bytes<MODE>();
 }
 template <int MODE>
-__global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PATHS_SCAN_WAVES : MODE == 2 ? PT_PATHS_GRID_WAVES : PT_PATHS_WIDE_WAVES) void k_paths(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
+__global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PATHS_SCAN_WAVES : PT_PATHS_GRID_WAVES) void k_paths(SceneTables sc, BatchInfo b, ptd::Queues qs, int32_t* __restrict__ cnt /* [depth][Q] rows */,
                                                                ptd::PathBuf in, ptd::RetireBuf ret) {
   extern __shared__ float4 lds_raw[];
   char* lds = reinterpret_cast<char*>(lds_raw);
-  const int nb_top = MODE >= 2 ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk / the wide tree replace top list and subtrees
+  const int nb_top = MODE == 2 ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk replaces top list and subtrees
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
   stage16(lds, sc.top, nb_top);
   stage16(lds + nb_top, sc.mats, nb_mats);
@@ -1510,15 +1509,8 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
     lnodes = lds + tbl;
     tbl += nb_nodes;
   }
-  if (MODE == 3 && sc.wide_lds > 0) {  // the wide tree's nodes (a few hundred primitives: the walk's fetches stay on the CU)
-    const int nb_wide = sc.num_wide * ptd::kWideWords * 16;
-    stage16(lds + tbl, sc.wide, nb_wide);
-    lnodes = lds + tbl;
-    tbl += nb_wide;
-  }
-  const int stack_bytes = MODE == 3 ? sc.wide_stack * 128 : 0;
-  const int wave_bytes = paths_wave_bytes<MODE>() + stack_bytes;
-  const int core_bytes = wave_bytes - paths_extra_bytes<MODE>();
+  constexpr int wave_bytes = paths_wave_bytes<MODE>();
+  constexpr int core_bytes = wave_bytes - paths_extra_bytes<MODE>();
   const int he = iter_hash_entries(sc);
   uint32_t* tword = reinterpret_cast<uint32_t*>(lds + tbl + kWavesPerBlock * wave_bytes);  // MODE 0: [kMaxTop] leaf | geom << 8 per top entry
   int* lmat = reinterpret_cast<int*>(tword + (MODE == 0 ? kMaxTop : 0));                    // MODE 0: [64] material of the leaf at threaded node index i
@@ -1542,14 +1534,6 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   if (MODE == 2) cb.gix = cr.ent + kCellRing, cr.rinv = reinterpret_cast<float*>(cr.ent + kCellRing + kRing);
   cb.debug = b.debug;
   cb.lnodes = (const __attribute__((address_space(3))) v4f*)(lnodes ? lnodes : lds), cb.lds_nodes = lnodes != nullptr;
-  Wide wd;  // MODE 3 (the same bytes)
-  wd.best = cy.best, wd.rec = cy.rec;
-  wd.ent = reinterpret_cast<uint32_t*>(wbase + 64 * 8 + 6 * 64 * 4), wd.gix = wd.ent + kRing;
-  wd.stack = reinterpret_cast<uint16_t*>(wbase + kWideCoreBytes), wd.cap = sc.wide_stack;
-  wd.head = wd.count = wd.appended = wd.processed = 0;
-  RayInv wri = ray_inv(mk(1.f, 1.f, 1.f), mk(0.f, 0.f, 0.f));  // MODE 3 lane state: reciprocal direction of the lane's ray, current node, stack fill, walking
-  int wcur = 0, wsp = 0;
-  bool trav = false;
   constexpr bool SLOTS = paths_slots_in_lds<MODE>();
   char* slots = wbase + core_bytes;  // SLOTS: [64] x 16 B, [64] x 16 B, [64] x 4 B, [64] x 4 B
   int* died = reinterpret_cast<int*>(slots + (SLOTS ? kSlotBytes : 0));  // [64]: paths of this wave retired AT depth d (statistics; PT_MAX_DEPTH = 64)
@@ -1718,33 +1702,6 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
         paths_chunk(cy, cy.count, lane, o, d, tword, geoms);  // count < 64 here
         ready = valid;
       }
-    } else if constexpr (MODE == 3) {
-      // ── wide-tree walk: lanes with a new ray start at the root; every walking lane steps until half of the live lanes are
-      //    resolved (finished and every candidate of theirs tested) or nobody walks any more ──
-      if (fresh) {
-        wri = ray_inv(d, o);
-        wd.best[lane] = kNoHit;
-        mark = wd.processed;  // no candidate yet: resolved once the walk ends
-        wcur = 0, wsp = 0;
-        trav = true;
-      }
-      PT_STAT(14, 1);
-      PT_STAT(15, __popcll(ballot(valid)));
-      const int nv = (int)__popcll(ballot(valid));
-      int nt;
-      while (true) {
-        nt = (int)__popcll(ballot(trav));
-        ready = valid && !trav && (wd.processed - mark) >= 0;
-        if (nt == 0 || 2 * (int)__popcll(ballot(ready)) >= nv) break;
-        if (lnodes) wide_step(wd, (const __attribute__((address_space(3))) v4f*)lnodes, o, d, wri, trav, wcur, wsp, sc.cull_margin, lane, mark, geoms);
-        else wide_step(wd, reinterpret_cast<const v4f*>(sc.wide), o, d, wri, trav, wcur, wsp, sc.cull_margin, lane, mark, geoms);
-      }
-      if (nt == 0 && wd.count > 0 && 2 * (int)__popcll(ballot(ready)) < nv) {  // nobody walks and too few are resolved: the pending candidates as a partial chunk
-        PT_STAT(3, 1);
-        wide_chunk(wd, wd.count, lane, o, d, geoms);  // count < 64 here
-        ready = valid;
-      }
-      PT_STAT(13, __popcll(ballot(ready)));
     } else {
       // ── search of every live lane (all of them have a new ray), then all its candidates ──
       cb.best[lane] = kNoHit;
@@ -1784,7 +1741,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
           } else {
             const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
             hmat = G->material;
-            if (MODE >= 2) hn = finish_normal(G, hn);  // the grid's / the wide walk's chunks leave the normal to the winner (carry_chunk LEAN, wide_chunk)
+            if (MODE == 2) hn = finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
           }
         }
         const uint32_t ih = he > 0 ? ihash[(depth - 1) * he + k] : iter_hash(b.iter_first + k, depth);

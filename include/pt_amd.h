@@ -99,8 +99,7 @@ typedef struct PtOptions {
   int32_t debug_flags;      /* A-B switches with UNCHANGED results: 16 no closer-hit cull in the subtree scans, 32 no
                                near-first subtree order, 256 / 512 force / forbid the uniform-grid walk of the fused kernels
                                (default: for large scenes, whichever of the BVH scan and up to three grid resolutions renders a
-                               few iterations fastest at pt_init), 1024 / 4096 force / forbid the 4-wide tree walk of depths >= 1 (default: every scene of more than 32
-                               primitives that is not on the grid), 2048 keep the reference's leaf boxes for spheres (default for
+                               few iterations fastest at pt_init), 2048 keep the reference's leaf boxes for spheres (default for
                                large scenes: tightened to the ellipsoid's box, PtStats.tight_leaves; pt_stage_intersect on such
                                a scene then expects ray origins inside the scene bounds or at the camera).  Bits 0-3 are
                                profiling ablations with WRONG results (1 no top list, 4 skip the primitive tests, 8 skip the
@@ -157,8 +156,7 @@ typedef struct PtStats {
                                          which it beat the BVH scan at pt_init) with this many cells; 0: the BVH         */
   int32_t tight_leaves;               /* sphere leaves whose traversal box was tightened from the reference's box of the
                                          transformed unit cube to the box of the ellipsoid (large scenes; same image)     */
-  int32_t wide_nodes;                 /* > 0: depths >= 1 walk the 4-wide surface-area tree of our own over the leaf boxes
-                                         (scenes of more than 32 primitives that are not on the grid) with this many nodes  */
+  int32_t reserved0;
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,
@@ -199,24 +197,6 @@ typedef struct PtGridRecord {
                              bits 6-7: primitive type; bits 8-31: index of the primitive in PtSceneDesc.geoms  */
 } PtGridRecord;
 int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* info, uint32_t* cell_start, PtGridRecord* records);
-
-/* The traversal structure of our own for scenes of more than 32 primitives that are not on the grid (SURVEY.md section 8
- * f-2: "SAH or wide nodes"; the reference has only the median-split binary tree of pathtrace.cu:52-111): a 4-wide BVH over the
- * leaf boxes of the reference's tree, built with the surface-area heuristic (full sweep, three axes) and collapsed to four
- * children per node; depths >= 1 walk it per lane with a stack (csrc/pt_wide.inc).  The image is the same: a leaf's child
- * record carries the leaf's own box bit for bit, inner boxes are exact unions, and the closest hit is decided by (t, index of
- * the leaf in the reference's visiting order).  Host-only (no GPU needed).  Node i = 28 floats: bmin.x[4] bmin.y[4] bmin.z[4]
- * bmax.x[4] bmax.y[4] bmax.z[4] link[4] (child-major); link (int32) > 0: inner node index (node 0 is the root), 0: no child,
- * bit 31 set: leaf — bits 0-14 its index in the reference's visiting order (threaded BVH), bits 15-28 the index of the
- * primitive in PtSceneDesc.geoms, bits 29-30 its type.  Uses the reference's leaf boxes (tighten == 0) or the boxes of
- * pt_traversal_boxes (tighten != 0, what pt_init uses from 64 BVH nodes on).  Returns the node count (0: the scene is outside
- * the link fields' ranges — more than 16384 primitives), writes up to cap_nodes nodes if `nodes` != NULL. */
-typedef struct PtWideInfo {
-  int32_t num_nodes, num_leaves;
-  int32_t max_stack; /* most entries a lane's stack holds during any walk of this tree */
-  int32_t reserved;
-} PtWideInfo;
-int pt_build_wide(const PtGeom* geoms, int num_geoms, int tighten, const float camera_position[3], PtWideInfo* info, float* nodes, int cap_nodes);
 
 /* Host-only: the box our traversal structures test for each geom's leaf — the reference's leaf box (pathtrace.cu:36-50),
  * except for spheres of large scenes, where it is intersected with the box of the ellipsoid itself (grown by a bound on
