@@ -1096,6 +1096,8 @@ PT_DEV void carry_search(Carry<!SUB, NPAR>& c, const float4* top, int ntop, cons
     const int t_link = __builtin_amdgcn_readfirstlane(__float_as_int(TB.w));
     const bool pass = valid && slab(o, ri, TA.x, TA.y, TA.z, TA.w, TB.x, TB.y);
     PT_STAT(8, __popcll(ballot(pass)));
+    // (the closer-hit cull on top entries that are leaves — scenes of a few dozen primitives, where all of them are — was measured:
+    // 32 primitives 9.9 -> 9.2 k Msamples/s; the list is not in near-first order and every entry pays the LDS read of the best hit)
     if (t_link < 0) carry_append(c, pass, (uint32_t)t_idx, par, lane, lane, nodes, geoms);
     else if (pass) pend |= 1u << e;
   }

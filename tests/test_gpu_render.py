@@ -380,6 +380,11 @@ def test_c5_stress_scene_rows_bit_exact(oracle, tmp_path):
     (4, 300, False, (128, 80), 4, dict(debug_flags=256)),
     (6, 1500, True, (128, 80), 3, dict(debug_flags=256)),
     (8, 5000, False, (160, 96), 2, dict(debug_flags=256)),
+    # grid forbidden (512) on the large ones: depth 0 as ONE wave-uniform scan of the threaded tree per group (trace_group_packet),
+    # depths >= 1 as top list + per-lane subtree scans
+    (6, 1500, True, (128, 80), 3, dict(debug_flags=512)),
+    (8, 5000, False, (160, 96), 2, dict(debug_flags=512)),
+    (9, 150, False, (200, 120), 3, dict(debug_flags=512, iters_per_batch=1)),
 ])
 def test_random_scenes_bit_exact(oracle, tmp_path, seed, n, clustered, res, spp, kw):
     """Fuzz: random rotations about all axes, non-uniform scales, objects poking through the walls, mixed materials
