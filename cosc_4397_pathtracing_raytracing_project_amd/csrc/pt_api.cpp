@@ -89,6 +89,10 @@ struct PtContext {
   ptd::Geom* d_geoms = nullptr;
   ptd::Mat* d_mats = nullptr;
   ptd::TopEntry* d_top = nullptr;
+  // the bounce kernels' box tables (SceneTables::*_b): the same buffers, except for the fast build (centre / half extent copies)
+  ptd::Node* d_nodes_b = nullptr;
+  ptd::TopEntry* d_top_b = nullptr;
+  ptd::Node* d_grid_items_b = nullptr;
   int num_nodes = 0, num_top = 0;
   float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
   float cull_margin = 0.f;
@@ -107,6 +111,7 @@ struct PtContext {
     uint32_t* d_start;
     size_t guard;
     ptd::Node* d_items;
+    ptd::Node* d_items_b;  // == d_items unless the build wants centre / half extent
     int res[3];
     float gmin[3], cs[3], inv_cs[3], pad;
     size_t bytes;
@@ -515,6 +520,23 @@ bool build_grid(const std::vector<ptd::Node>& nodes, const std::vector<PtGeom>& 
   return true;
 }
 
+// A box as centre and half extent for the fast build's slab test (pt_arith.inc slab_t): the centre rounded to float, the half
+// extent rounded UP from the distance to the farther face (so the converted box contains the original in real arithmetic), in
+// place in (bmin, bmax).  `inner` (inner nodes, subtree entries of the top list — pure acceleration): a little more, so that in the
+// test's float arithmetic a ray that passes a leaf's box still passes every box above it (1e-5 of the box and of the
+// coordinates: two orders of magnitude above the rounding of the three FMAs).
+void center_half_box(float bmin[3], float bmax[3], bool inner) {
+  for (int a = 0; a < 3; ++a) {
+    const double lo = bmin[a], hi = bmax[a];
+    const float c = (float)(0.5 * (lo + hi));
+    double h = std::max(hi - (double)c, (double)c - lo);
+    if (inner) h = h * (1.0 + 1e-5) + 1e-5 * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30;
+    float hf = (float)h;
+    if ((double)hf < h) hf = std::nextafter(hf, INFINITY);
+    bmin[a] = c, bmax[a] = hf;
+  }
+}
+
 ptk::SceneTables tables(const Ctx& g) {
   ptk::SceneTables t{};
   t.nodes = g.d_nodes;
@@ -524,6 +546,9 @@ ptk::SceneTables tables(const Ctx& g) {
   t.mats = g.d_mats;
   t.num_mats = (int)g.mats.size();
   t.top = g.d_top;
+  t.nodes_b = g.d_nodes_b ? g.d_nodes_b : g.d_nodes;
+  t.top_b = g.d_top_b ? g.d_top_b : g.d_top;
+  t.grid_items_b = nullptr;
   t.num_top = (kAblateBuild && (g.debug_flags & 1)) ? 0 : g.num_top;
   std::memcpy(t.root_min, g.root_min, 12);
   std::memcpy(t.root_max, g.root_max, 12);
@@ -543,6 +568,7 @@ ptk::SceneTables tables(const Ctx& g) {
     t.lds_table_bytes = -1;  // (a forced grid on a small scene: the grid kernels read the tables from memory)
     t.grid_start = g.d_grid_start + g.grid_guard;
     t.grid_items = g.d_grid_items;
+    t.grid_items_b = g.d_grid_items_b ? g.d_grid_items_b : g.d_grid_items;
     for (int a = 0; a < 3; ++a)
       t.grid_res[a] = g.grid_res[a], t.grid_min[a] = g.grid_min[a], t.grid_cs[a] = g.grid_cs[a], t.grid_inv_cs[a] = g.grid_inv_cs[a];
     t.grid_pad = g.grid_pad;
@@ -669,7 +695,7 @@ void plan_launch(Ctx& g) {
 // Make candidate i the grid the kernels walk.
 void use_grid_alt(Ctx& g, size_t i) {
   const Ctx::GridAlt& a = g.grid_alts[i];
-  g.d_grid_start = a.d_start, g.grid_guard = a.guard, g.d_grid_items = a.d_items;
+  g.d_grid_start = a.d_start, g.grid_guard = a.guard, g.d_grid_items = a.d_items, g.d_grid_items_b = a.d_items_b;
   for (int k = 0; k < 3; ++k) g.grid_res[k] = a.res[k], g.grid_min[k] = a.gmin[k], g.grid_cs[k] = a.cs[k], g.grid_inv_cs[k] = a.inv_cs[k];
   g.grid_pad = a.pad;
   g.have_grid = true;
@@ -683,7 +709,8 @@ int choose_traversal(Ctx& g) {
   auto drop_unused_grids = [&](size_t keep) {
     for (size_t i = 0; i < g.grid_alts.size(); ++i) {
       if (i == keep) continue;
-      for (void* p : {(void*)g.grid_alts[i].d_start, (void*)g.grid_alts[i].d_items}) {
+      for (void* p : {(void*)g.grid_alts[i].d_start, (void*)g.grid_alts[i].d_items, g.grid_alts[i].d_items_b != g.grid_alts[i].d_items ? (void*)g.grid_alts[i].d_items_b : nullptr}) {
+        if (!p) continue;
         (void)hipFree(p);
         g.allocs.erase(std::remove(g.allocs.begin(), g.allocs.end(), p), g.allocs.end());
       }
@@ -932,6 +959,15 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemcpy(g.d_nodes, nodes.data(), nodes.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_geoms, dg.data(), dg.size() * sizeof(ptd::Geom), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(g.d_mats, dm.data(), dm.size() * sizeof(ptd::Mat), hipMemcpyHostToDevice));
+  if (g.k->boxes_center_half) {  // the fast build: converted copies for the bounce kernels
+    std::vector<ptd::Node> nb = nodes;
+    for (ptd::Node& n : nb) center_half_box(n.bmin, n.bmax, n.geom < 0);
+    std::vector<ptd::TopEntry> tb = top;
+    for (ptd::TopEntry& e : tb) center_half_box(e.bmin, e.bmax, e.link >= 0);
+    if (dalloc(g, &g.d_nodes_b, nb.size()) || dalloc(g, &g.d_top_b, tb.size())) return -1;
+    HIP_OK(hipMemcpy(g.d_nodes_b, nb.data(), nb.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(g.d_top_b, tb.data(), tb.size() * sizeof(ptd::TopEntry), hipMemcpyHostToDevice));
+  }
   if ((g.num_nodes >= kGridNodes || (g.debug_flags & 256)) && !(g.debug_flags & 512)) {
     const char* dens = getenv("PT_GRID_DENSITY");  // experiment knob: cells per primitive instead of the search
     double cam_mag = 0.0;
@@ -958,9 +994,16 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
       std::fill(padded.begin() + alt.guard + gb.start.size(), padded.end(), gb.start.back());
       const int64_t before = g.device_bytes;
       if (dalloc(g, &alt.d_start, padded.size()) || dalloc(g, &alt.d_items, gb.items.size())) return -1;
-      alt.bytes = (size_t)(g.device_bytes - before);
       HIP_OK(hipMemcpy(alt.d_start, padded.data(), padded.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
       HIP_OK(hipMemcpy(alt.d_items, gb.items.data(), gb.items.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
+      alt.d_items_b = alt.d_items;
+      if (g.k->boxes_center_half) {  // the grid's records are leaf boxes
+        std::vector<ptd::Node> ib = gb.items;
+        for (ptd::Node& n : ib) center_half_box(n.bmin, n.bmax, false);
+        if (dalloc(g, &alt.d_items_b, ib.size())) return -1;
+        HIP_OK(hipMemcpy(alt.d_items_b, ib.data(), ib.size() * sizeof(ptd::Node), hipMemcpyHostToDevice));
+      }
+      alt.bytes = (size_t)(g.device_bytes - before);
       for (int a = 0; a < 3; ++a) alt.res[a] = gb.res[a], alt.gmin[a] = gb.gmin[a], alt.cs[a] = gb.cs[a], alt.inv_cs[a] = gb.inv_cs[a];
       alt.pad = gb.pad;
       g.grid_alts.push_back(alt);

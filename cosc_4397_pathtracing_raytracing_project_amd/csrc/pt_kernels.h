@@ -52,6 +52,13 @@ struct SceneTables {
   int32_t use_grid;
   int32_t trace_depth;    // of the context (k_paths sizes its iteration-hash rows with it)
   int32_t has_triangles;  // mesh extension: some geoms are PT_GEOM_TRIANGLE (the sphere-only chunk specialisation is off)
+  // The box tables of the BOUNCE kernels (depths >= 1; depth 0 always reads the ones above with the reference's arithmetic).  The
+  // same tables, except in the fast build (KernelApi::boxes_center_half), whose slab test takes a box as centre and half extent
+  // (pt_arith.inc slab_t): there the host uploads converted copies — bmin = centre, bmax = half extent rounded up so that the
+  // box contains the original, inner nodes and subtree entries a little more (pt_api.cpp center_half_boxes).
+  const ptd::Node* nodes_b;
+  const ptd::TopEntry* top_b;
+  const ptd::Node* grid_items_b;
   int32_t scan_nodes_lds;  // k_paths mode 1: 1 = the threaded nodes are staged in LDS for the subtree scans (scenes of a few hundred nodes:
                            // 64 primitives +4 % Msamples/s), 0 = read from memory, -1 = staged when that costs no resident workgroup per CU (resolved at launch)
 };
@@ -133,6 +140,7 @@ struct KernelApi {
   // queue, survivors never leave their registers (pt_kernels.hip k_paths; LDS-table scenes).  cnt = the counter rows [depth][Q]:
   // row 1 is read (the queues' depth-1 rays), rows >= 2 receive the rays traced per depth.
   void (*paths)(hipStream_t s, int grid, const SceneTables& sc, const BatchInfo& b, const ptd::Queues& qs, int32_t* cnt, ptd::PathBuf in, ptd::RetireBuf ret);
+  int boxes_center_half;  // 1: the bounce kernels of this build expect SceneTables::*_b as centre / half extent (the fast build)
 };
 const KernelApi* api_exact();
 const KernelApi* api_fma();

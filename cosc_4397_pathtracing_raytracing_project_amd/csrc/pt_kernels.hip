@@ -587,11 +587,11 @@ __global__ __launch_bounds__(kBlock) void k_intersect_legacy(SceneTables sc, ptd
                                                              const int32_t* __restrict__ cnt_in, ptd::PathBuf paths,
                                                              ptd::HitBuf hits) {
   extern __shared__ float4 lds_raw[];
-  const ptd::Node* nodes = sc.nodes;
+  const ptd::Node* nodes = EX ? sc.nodes : sc.nodes_b;  // EX: primary rays, the reference's arithmetic on the reference's boxes; else the build's bounce tables
   const ptd::Geom* geoms = sc.geoms;
   if (TABLES_IN_LDS) {
     char* base = reinterpret_cast<char*>(lds_raw);
-    stage16(base, sc.nodes, sc.num_nodes * (int)sizeof(ptd::Node));
+    stage16(base, nodes, sc.num_nodes * (int)sizeof(ptd::Node));
     stage16(base + sc.num_nodes * sizeof(ptd::Node), sc.geoms, sc.num_geoms * (int)sizeof(ptd::Geom));
     __syncthreads();
     nodes = reinterpret_cast<const ptd::Node*>(base);
@@ -845,15 +845,15 @@ __global__ __launch_bounds__(kBlock) void k_intersect(SceneTables sc, ptd::Queue
   char* lds = reinterpret_cast<char*>(lds_raw);
   // LDS map: [top list][nodes][geoms] (tables, if they fit) then one WaveLds block per wave
   const int nb_top = sc.num_top * (int)sizeof(ptd::TopEntry);
-  stage16(lds, sc.top, nb_top);
+  stage16(lds, EX ? sc.top : sc.top_b, nb_top);  // EX: primary rays, the reference's arithmetic on the reference's boxes; else the build's bounce tables
   const float4* top = reinterpret_cast<const float4*>(lds);
-  const ptd::Node* nodes = sc.nodes;
+  const ptd::Node* nodes = EX ? sc.nodes : sc.nodes_b;
   const ptd::Geom* geoms = sc.geoms;
   int tbl = nb_top;
   if (TABLES_IN_LDS) {
     const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
     const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
-    stage16(lds + nb_top, sc.nodes, nb_nodes);
+    stage16(lds + nb_top, nodes, nb_nodes);
     stage16(lds + nb_top + nb_nodes, sc.geoms, nb_geoms);
     nodes = reinterpret_cast<const ptd::Node*>(lds + nb_top);
     geoms = reinterpret_cast<const ptd::Geom*>(lds + nb_top + nb_nodes);
@@ -1542,12 +1542,12 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   char* lds = reinterpret_cast<char*>(lds_raw);
   const int nb_top = MODE == 2 ? 0 : sc.num_top * (int)sizeof(ptd::TopEntry);  // the grid walk replaces top list and subtrees
   const int nb_mats = (sc.num_mats * (int)sizeof(ptd::Mat) + 15) & ~15;
-  stage16(lds, sc.top, nb_top);
+  stage16(lds, sc.top_b, nb_top);  // the bounce kernels' box tables (SceneTables::*_b)
   stage16(lds + nb_top, sc.mats, nb_mats);
   const float4* top = reinterpret_cast<const float4*>(lds);
   const ptd::Mat* mats = reinterpret_cast<const ptd::Mat*>(lds + nb_top);
   int tbl = nb_top + nb_mats;
-  const ptd::Node* nodes = sc.nodes;
+  const ptd::Node* nodes = sc.nodes_b;
   const ptd::Geom* geoms = sc.geoms;
   if (MODE == 0) {  // the geometry records; of the nodes only tword / lmat below are needed (every leaf is a top entry)
     const int nb_geoms = sc.num_geoms * (int)sizeof(ptd::Geom);
@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const char* lnodes = nullptr;
   if (MODE == 1 && sc.scan_nodes_lds > 0) {
     const int nb_nodes = sc.num_nodes * (int)sizeof(ptd::Node);
-    stage16(lds + tbl, sc.nodes, nb_nodes);
+    stage16(lds + tbl, sc.nodes_b, nb_nodes);
     lnodes = lds + tbl;
     tbl += nb_nodes;
   }
@@ -1746,7 +1746,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
     if constexpr (MODE == 0) {
       // ── search: box tests + appends for the lanes with a new ray; full chunks as the ring fills ──
       if (ballot(fresh)) {
-        if constexpr (PT_TOP_SCALAR != 0) paths_search(cy, (cfloat4*)(uintptr_t)sc.top, tword, ntop, geoms, o, d, fresh, lane, mark);
+        if constexpr (PT_TOP_SCALAR != 0) paths_search(cy, (cfloat4*)(uintptr_t)sc.top_b, tword, ntop, geoms, o, d, fresh, lane, mark);
         else paths_search(cy, top, tword, ntop, geoms, o, d, fresh, lane, mark);
       }
       // ── which lanes are resolved?  Too few, with candidates pending: run them as a partial chunk ──
@@ -1858,7 +1858,8 @@ const KernelApi kApi = {
     "fast",
 #endif
     launch_generate, launch_primary, launch_intersect, launch_shade, launch_collect, launch_count_stats,
-    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check, launch_paths};
+    launch_preview, launch_save_u8, launch_shade_stage, lds_table_limit, resident_blocks_per_cu, launch_ieee_check, launch_paths,
+    md::kFastSlab ? 1 : 0};
 
 }  // namespace
 }  // namespace PT_NS
