@@ -1481,6 +1481,8 @@ PT_DEV void paths_search(Lanes& c, TOP* top, const uint32_t* tword, int ntop, co
   // box tests, eight at a time fully unrolled (no loop-carried box registers to rotate); bit (ntop - 1 - e) of the mask = entry e
   uint32_t mask = 0;
   {
+    // (fetching four boxes together before testing them — one wait for four scalar loads instead of one per box — was measured in
+    // the fast build: k_paths 1292 -> 1315 us, 32 more SGPRs in flight and 19 spilled)
     for (int e0 = 0; e0 < ntop; e0 += 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
