@@ -105,6 +105,9 @@ def lib() -> C.CDLL:
         L.pt_selfcheck_ieee.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
     if hasattr(L, "pt_traversal_boxes"):  # absent from older A/B builds of the library (tools/build_rev.sh)
         L.pt_traversal_boxes.argtypes = [C.POINTER(PtGeom), C.c_int, _fp, _fp]
+    if hasattr(L, "pt_center_half_box"):
+        L.pt_center_half_box.argtypes = [_fp, _fp, C.c_int, _fp, _fp]
+        L.pt_center_half_box.restype = None
     L.pt_build_transform.argtypes = [_fp, _fp, _fp, _fp]
     L.pt_init.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtOptions)]
     L.pt_render.argtypes = [C.c_int, C.c_int]

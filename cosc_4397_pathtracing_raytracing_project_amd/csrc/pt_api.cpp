@@ -1144,6 +1144,13 @@ int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* in
   return 1;
 }
 
+void pt_center_half_box(const float lo[3], const float hi[3], int inner, float center[3], float half_extent[3]) {
+  float a[3] = {lo[0], lo[1], lo[2]}, b[3] = {hi[0], hi[1], hi[2]};
+  center_half_box(a, b, inner != 0);
+  std::memcpy(center, a, 12);
+  std::memcpy(half_extent, b, 12);
+}
+
 int pt_build_transform(const float* trs, float* transform, float* inverse, float* invTranspose) {
   if (!trs || !transform || !inverse || !invTranspose) return fail("pt_build_transform: null argument");
   pt::buildTransform(trs, transform, inverse, invTranspose);

@@ -206,6 +206,14 @@ int pt_build_grid(const PtGeom* geoms, int num_geoms, int forced, PtGridInfo* in
  * Returns the number of tightened leaves (pt_init applies it from 64 BVH nodes on; PtOptions.debug_flags 2048 turns it off). */
 int pt_traversal_boxes(const PtGeom* geoms, int num_geoms, const float camera_position[3], float* boxes);
 
+/* Host-only: a traversal box as the FAST build's bounce kernels test it — centre and half extent instead of min / max, so that
+ * the slab test is three FMAs per axis (csrc/pt_arith.inc slab_t; min / max issue at half the rate of an FMA on gfx950).  The
+ * half extent is rounded up from the distance between the float centre and the farther face, so [c - h, c + h] contains
+ * [lo, hi] in real arithmetic; `inner` != 0 (inner nodes, subtree entries of the top list: pure acceleration) adds 1e-5 of the
+ * extent and of the coordinates, so that a ray passing a leaf's box in the test's float arithmetic passes every box above it.
+ * Depth 0 and the exact / fma builds test the reference's min / max boxes with the reference's arithmetic. */
+void pt_center_half_box(const float lo[3], const float hi[3], int inner, float center[3], float half_extent[3]);
+
 /* transform / inverse / inverse-transpose of an OBJECT block's TRANS ROTAT SCALE
  * (trs[9]), as utilityCore::buildTransformationMatrix + glm::inverse +
  * glm::inverseTranspose compute them (src/utilities.cpp:64-72, src/scene.cpp:83-86). */
