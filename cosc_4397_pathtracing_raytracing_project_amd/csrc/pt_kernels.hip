@@ -1620,10 +1620,30 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   int ce = ne, ck = 0, crho = 0, cstart = total, ccnt = 0, clist = 0, crec = 0;  // cursor (wave-uniform): sub-list e = ck * wq0 + crho; an empty slice leaves it at the end
   int cord = 0;          // how many sub-lists the cursor has been in before this one
   bool append = true;    // wave-uniform, see below
+  // A window of 64 consecutive sub[] words in registers (lane l holds sub[win0 + l]): the cursor reads counts and retiree numbers
+  // with v_readlane instead of a dependent global load per sub-list.  With a whole 1080p frame a wave's slice touches ~25
+  // sub-lists of ~1000 paths; with an eighth of it (eight GPUs, ~190 iterations per batch) ~160 sub-lists of ~25, a fifth of
+  // them empty, and two memory round trips per sub-list were a fifth of the kernel's time.
+  int win0 = -64;  // nothing loaded yet: no index e >= 0 lies in [-64, 0)
+  unsigned long long wsub = 0ull;
+  auto window_to = [&](int e) {  // make sub[e] available (wave-uniform e)
+    if (e < win0 || e >= win0 + 64) {
+      win0 = e;
+      wsub = (e + lane < ne) ? rt.sub[e + lane] : 0ull;
+    }
+  };
+  auto sub_word = [&](int e) -> unsigned long long {  // sub[e] for a wave-uniform e inside the window
+    const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wsub, e - win0);
+    const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wsub >> 32), e - win0);
+    return ((unsigned long long)hi32 << 32) | lo32;
+  };
+  window_to(0);
   auto cursor_bases = [&](int first_rank) {
     const int sub0 = ck * rt.seg_cap + sub_offset(quo, rem, crho) * 64;
     clist = sub0;
-    crec = sub0 + __builtin_amdgcn_readfirstlane((int)(uint32_t)(rt.sub[min(ce, ne - 1)] >> 32));
+    const int ec = min(ce, ne - 1);
+    window_to(ec);
+    crec = sub0 + (int)(uint32_t)(sub_word(ec) >> 32);
     if (lane == 0) fillc[cord & 63] = crec + (first_rank - cstart);  // where this wave's first record of the sub-list goes
   };
   if (lo < hi) {
@@ -1663,12 +1683,21 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       if (in) at = clist + (rank - cstart), rs = append ? (cord & 63) : crec + (rank - cstart);
       pending = pending && !in;
       if (!ballot(pending) || ce >= ne) break;
-      cstart += ccnt;  // on to the next sub-list that holds anything
-      do {
-        ++ce;
-        if (++crho == wq0) crho = 0, ++ck;
-        ccnt = __builtin_amdgcn_readfirstlane(count_of(ce));
-      } while (ce < ne && ccnt == 0);
+      cstart += ccnt;  // on to the next sub-list that holds anything: the first non-empty one behind ce in the window, else the window moves on
+      ccnt = 0;
+      int nxt = ce + 1;
+      while (nxt < ne) {
+        window_to(nxt);
+        const unsigned long long holds = ballot((uint32_t)wsub != 0u) & (~0ull << (nxt - win0));
+        if (holds) {
+          nxt = win0 + (int)__builtin_ctzll(holds);
+          ccnt = (int)(uint32_t)sub_word(nxt);
+          break;
+        }
+        nxt = win0 + 64;
+      }
+      ce = min(nxt, ne);
+      ck = ce / wq0, crho = ce - ck * wq0;
       ++cord;
       cursor_bases(cstart);
     }
