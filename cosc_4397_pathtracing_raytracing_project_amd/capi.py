@@ -70,7 +70,7 @@ class PtStats(C.Structure):
                 ("intersect_ms", C.c_double), ("render_ms", C.c_double), ("num_cus", C.c_int32),
                 ("grid_blocks", C.c_int32), ("num_queues", C.c_int32), ("iters_per_batch", C.c_int32),
                 ("device_bytes", C.c_int64), ("primary_fused", C.c_int32), ("bounces_fused", C.c_int32),
-                ("arith", C.c_int32), ("grid_cells", C.c_int32), ("tight_leaves", C.c_int32), ("reserved0", C.c_int32)]
+                ("arith", C.c_int32), ("grid_cells", C.c_int32), ("tight_leaves", C.c_int32), ("paths_waves", C.c_int32)]
 
 
 class PtError(RuntimeError):

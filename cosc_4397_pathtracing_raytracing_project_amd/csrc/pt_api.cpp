@@ -690,6 +690,7 @@ void plan_launch(Ctx& g) {
   g.grid_primary = g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPrimary, t));
   g.ret.wq0 = g.grid_primary * ptk::kWavesPerBlock / g.qs.Q;  // the sub-lists' residue count (pt_device.h RetireBuf)
   g.grid_paths = (g.fuse_bounces && g.depth > 1) ? g.num_cus * std::min(g.cap_bpc, g.k->resident_blocks_per_cu(ptk::kPaths, t)) : 0;
+  g.qs.paths_W = g.grid_paths * ptk::kWavesPerBlock;  // what k_count_stats deals to the queues (a table made for another width is ignored)
 }
 
 // Make candidate i the grid the kernels walk.
@@ -1027,6 +1028,10 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   if (dalloc(g, &g.d_cnt, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride)) return -1;
   HIP_OK(hipMemset(g.d_cnt, 0, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride * sizeof(int32_t)));  // k_count_stats re-zeroes it after every batch
   if (dalloc(g, &g.d_stats, PT_MAX_DEPTH)) return -1;
+  if (!getenv("PT_NO_DEAL")) {  // (A/B knob: W / Q waves per queue in every batch; same image)
+    if (dalloc(g, &g.qs.deal, 2 * (size_t)Q + 1)) return -1;
+    HIP_OK(hipMemset(g.qs.deal, 0, (2 * (size_t)Q + 1) * sizeof(int32_t)));  // nothing measured yet: W / Q each
+  }
   HIP_OK(hipMemset(g.d_image, 0, 3 * (size_t)g.N * sizeof(float)));
   HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));
   HIP_OK(hipDeviceSynchronize());
@@ -1307,7 +1312,16 @@ int pt_ctx_get_stats(PtContext* c, PtStats* out) {
   out->arith = g.arith;
   out->grid_cells = (tables(g).use_grid && g.fuse_bounces) ? g.grid_res[0] * g.grid_res[1] * g.grid_res[2] : 0;
   out->tight_leaves = g.tight_leaves;
-  out->reserved0 = 0;
+  out->paths_waves = 0;
+  if (g.qs.deal && g.grid_paths > 0) {  // the table the NEXT batch's k_paths launch will read (ptd::Queues::deal)
+    std::vector<int32_t> first((size_t)g.qs.Q + 1);
+    HIP_OK(hipMemcpy(first.data(), g.qs.deal, first.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (first[g.qs.Q] == g.qs.paths_W) {
+      int lo = first[1] - first[0], hi = lo;
+      for (int q = 1; q < g.qs.Q; ++q) lo = std::min(lo, first[q + 1] - first[q]), hi = std::max(hi, first[q + 1] - first[q]);
+      out->paths_waves = std::min(lo, 0xffff) << 16 | std::min(hi, 0xffff);
+    }
+  }
   return 0;
 }
 

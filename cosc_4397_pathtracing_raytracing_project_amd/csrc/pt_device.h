@@ -147,6 +147,14 @@ struct Queues {
   int32_t cnt_stride;   // ints between consecutive queue counters (64-B padding)
   int32_t nq;           // chunks per queue and iteration: ceil(ceil(N / 64) / Q)
   float inv_nq;         // 1.0f / nq (divmod)
+  // k_paths' waves dealt to the queues by MEASURED work (null: W / Q each).  A queue owns the same pixels in every iteration, so
+  // the rays its paths cost repeat from batch to batch, and with a small tile (a rank's share of a frame) they differ by
+  // +-25 % between queues.  deal[0 .. Q] = first wave of queue q (deal[Q] = the W the table was made for: any other launch
+  // width falls back to W / Q each), deal[Q + 1 + q] = rays traced for queue q by the k_paths launch of this batch, from which
+  // k_count_stats deals the next batch's waves.  Which wave traces a path changes no sample (RetireBuf).
+  int32_t* deal;
+  int32_t paths_W;      // waves of the k_paths launches (what k_count_stats deals)
+  int32_t pad;
 };
 
 }  // namespace ptd

@@ -1597,7 +1597,16 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wib);  // (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
   const int lane = lane_id();
   died[lane] = 0;
-  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  // Which queue the wave serves, as which of how many: W / Q waves per queue, or — once a batch has been measured — the
+  // queue's share of the W waves by the rays its paths cost in the previous batch (ptd::Queues::deal).
+  int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
+  if (qs.deal != nullptr && qs.deal[qs.Q] == qs.W) {
+    int at_or_before = 0;  // first[] is strictly increasing: the queues whose first wave is <= this wave
+    for (int e0 = 0; e0 < qs.Q; e0 += 64) at_or_before += (int)__popcll(ballot(e0 + lane < qs.Q && qs.deal[e0 + lane] <= wave));
+    q = at_or_before - 1;
+    const int first = qs.deal[q];
+    r = wave - first, wq = qs.deal[q + 1] - first;
+  }
   const Retire rt = retire_of(ret, q);
   const size_t per_depth = (size_t)qs.Q * qs.cnt_stride;
   const int64_t qbase = (int64_t)q * qs.cap;
@@ -1608,11 +1617,22 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const int wq0 = rt.wq0, ne = b.K * wq0;
   const int my_nq = queue_share(b, qs, q).my_nq, quo = my_nq / wq0, rem = my_nq % wq0;
   auto count_of = [&](int e) { return e < ne ? (int)(uint32_t)rt.sub[e] : 0; };
-  int total = 0;
-  for (int e0 = 0; e0 < ne; e0 += 64) {
-    int sum;
-    (void)wave_prefix6(count_of(e0 + lane), sum);
-    total += sum;
+  // Every wave of the queue scans sub[] for the total and for where its slice begins.  With a small tile that is thousands of
+  // words (an eighth of 1080p: 195 iterations x 20 residues): the words are fetched four 64-entry chunks ahead of their
+  // reductions, and the chunk sums stay in a register (lane i: chunk i) so that the second scan starts at the slice's chunk.
+  int total = 0, csum = 0;
+  const bool chunk_sums = ne <= 64 * 64;
+  for (int e0 = 0; e0 < ne; e0 += 256) {
+    int n4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) n4[j] = count_of(e0 + 64 * j + lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int sum;
+      (void)wave_prefix6(n4[j], sum);
+      total += sum;
+      if (lane == (e0 >> 6) + j) csum = sum;
+    }
   }
   const int per = (total + wq - 1) / wq;
   const int lo = min(r * per, total), hi = min(lo + per, total);
@@ -1652,9 +1672,18 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
     // retirement through a counter per sub-list in LDS (fillc: lanes of one sub-list that die together get consecutive slots,
     // as the per-iteration counters of the earlier layouts gave) — while the slice touches at most 64 of them; beyond that
     // (tiles of a few pixels per wave) a path's record goes to the slot its own list index names.
-    int cum = 0, nsub = 0;
+    int cum = 0, nsub = 0, e_begin = 0;
     bool found = false;
-    for (int e0 = 0; e0 < ne && cum < hi; e0 += 64) {
+    if (chunk_sums) {  // the chunk rank lo lies in (lo < hi <= total: there is one)
+      int all;
+      const int cbefore = wave_prefix6(csum, all);
+      const unsigned long long here = ballot(csum > 0 && cbefore <= lo && lo < cbefore + csum);
+      if (here) {
+        const int l = __builtin_ctzll(here);
+        e_begin = l * 64, cum = __builtin_amdgcn_readlane(cbefore, l);
+      }
+    }
+    for (int e0 = e_begin; e0 < ne && cum < hi; e0 += 64) {
       const int n = count_of(e0 + lane);
       int sum;
       const int before = wave_prefix6(n, sum);
@@ -1844,11 +1873,13 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   }
   // statistics: rays traced at depth d >= 2 = this wave's paths retired at depth >= d (row 1 holds the queue's input count already)
   if (lane == 0) {
-    int reached = 0;
+    int reached = 0, rays = hi - lo;
     for (int dd = min(b.trace_depth - 1, 63); dd >= 2; --dd) {
       reached += died[dd];
+      rays += reached;
       if (reached) atomicAdd(&cnt[per_depth * dd + (size_t)q * qs.cnt_stride], reached);
     }
+    if (qs.deal != nullptr && rays) atomicAdd(&qs.deal[qs.Q + 1 + q], rays);  // what this queue's paths cost: the next batch's deal
   }
 }
 

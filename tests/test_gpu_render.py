@@ -163,6 +163,41 @@ def test_striped_tiles_compose(scene_dir):
         assert np.array_equal(bits(out.reshape(-1, 3)), bits(full))
 
 
+def test_waves_dealt_by_measured_work_change_no_sample(scene_dir, oracle, monkeypatch):
+    """k_paths' waves are dealt to the queues by the rays the queues' paths cost in the previous batch (ptd::Queues::deal): on a
+    rank's tile of an eight-way split the queues differ enough for the deal to take effect (PtStats.paths_waves), and the image
+    over several batches — the first with W / Q waves each, the rest dealt — is the oracle's bit for bit, and equal to the image
+    with the deal switched off.  A whole small frame with few queues: queues too close together, no deal."""
+    from cosc_4397_pathtracing_raytracing_project_amd import capi, parallel
+    res, spp = (640, 360), 12
+    w, h = res
+    o = parallel.striped_tile_for_rank(w, h, 0, 8)
+    sc = capi.Scene(scene_dir["cornell"], res=res)
+    imgs = {}
+    for deal in (True, False):
+        if not deal:
+            monkeypatch.setenv("PT_NO_DEAL", "1")
+        r = capi.Renderer(sc, iters_per_batch=3, **o)
+        try:
+            r.render(1, spp)
+            imgs[deal] = r.readback()
+            pw = r.stats().paths_waves
+        finally:
+            r.free()
+        if deal:
+            assert pw != 0 and (pw >> 16) >= 1 and (pw >> 16) < (pw & 0xffff), pw
+        else:
+            assert pw == 0
+    monkeypatch.delenv("PT_NO_DEAL")
+    assert np.array_equal(bits(imgs[True]), bits(imgs[False]))
+    oracle.set_math_mode(oracle.PORTABLE)
+    oracle.load_scene(scene_dir["cornell"], res=res)
+    rows = list(range(0, h, 8))[12:30:3]  # rows that look into the box
+    for row in rows:
+        ref = oracle.render(1, spp, depth=8, variant=oracle.RETIRE, nthreads=8, pix_begin=row * w, pix_count=w)
+        assert np.array_equal(bits(imgs[True].reshape(-1, w, 3)[row // 8]), bits(ref.reshape(-1, 3))), row
+
+
 @pytest.mark.parametrize("res,kw", [
     ((640, 360), dict(num_queues=4)),                        # 900 chunks per queue: k_collect takes 8 passes of 128 chunks
     ((640, 361), dict(num_queues=8, iters_per_batch=3)),     # odd row count: the tile's last chunk is partial; 3 batches + remainder

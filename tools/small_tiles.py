@@ -20,6 +20,7 @@ for world in worlds:
         line=f"world {world} tile {n} px K={r.stats().iters_per_batch:3d}:"
         for steps in (20, 2000):
             best=1e9
+            r.reset_stats()  # the k_paths average below: launches of the last leg only (whole batches)
             for rep in range(4):
                 r.clear(); r.sync()
                 t0=time.perf_counter(); r.render(1,steps); r.sync(); dt=time.perf_counter()-t0
