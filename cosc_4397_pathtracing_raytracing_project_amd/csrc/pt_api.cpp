@@ -608,6 +608,13 @@ int run_batch(Ctx& g, int iter_first, int kb) {
   b.aa_jitter = g.aa_jitter ? 1 : 0;
   b.debug = kAblateBuild ? g.debug_flags : 0;
   b.flat = g.fuse_bounces ? 0 : 1;
+  {
+    // k_primary's strands in pieces (BatchInfo::primary_pieces): a piece pays for its own pipeline drain, so it should hold a
+    // few dozen 64-sample groups; a wave's strand has K * nq / (waves per queue) of them
+    const char* e = getenv("PT_PRIMARY_PIECES");  // experiment knob
+    const int64_t groups = (int64_t)kb * g.qs.nq / std::max(1, g.ret.wq0);
+    b.primary_pieces = e ? atoi(e) : (int)std::min<int64_t>(4, std::max<int64_t>(1, groups / 48));
+  }
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;
   b.inv_stripe = g.stripe ? 1.0f / (float)g.stripe : 0.0f;
@@ -1029,8 +1036,8 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemset(g.d_cnt, 0, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride * sizeof(int32_t)));  // k_count_stats re-zeroes it after every batch
   if (dalloc(g, &g.d_stats, PT_MAX_DEPTH)) return -1;
   if (!getenv("PT_NO_DEAL")) {  // (A/B knob: W / Q waves per queue in every batch; same image)
-    if (dalloc(g, &g.qs.deal, 2 * (size_t)Q + 1)) return -1;
-    HIP_OK(hipMemset(g.qs.deal, 0, (2 * (size_t)Q + 1) * sizeof(int32_t)));  // nothing measured yet: W / Q each
+    if (dalloc(g, &g.qs.deal, 2 * (size_t)Q + 2)) return -1;
+    HIP_OK(hipMemset(g.qs.deal, 0, (2 * (size_t)Q + 2) * sizeof(int32_t)));  // nothing measured yet: W / Q each
   }
   HIP_OK(hipMemset(g.d_image, 0, 3 * (size_t)g.N * sizeof(float)));
   HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));

@@ -151,7 +151,8 @@ struct Queues {
   // the rays its paths cost repeat from batch to batch, and with a small tile (a rank's share of a frame) they differ by
   // +-25 % between queues.  deal[0 .. Q] = first wave of queue q (deal[Q] = the W the table was made for: any other launch
   // width falls back to W / Q each), deal[Q + 1 + q] = rays traced for queue q by the k_paths launch of this batch, from which
-  // k_count_stats deals the next batch's waves.  Which wave traces a path changes no sample (RetireBuf).
+  // k_count_stats deals the next batch's waves.  Which wave traces a path changes no sample (RetireBuf).  deal[2 Q + 1]: the
+  // counter k_primary's waves take the later pieces of the strands from (BatchInfo::primary_pieces), zero between batches.
   int32_t* deal;
   int32_t paths_W;      // waves of the k_paths launches (what k_count_stats deals)
   int32_t pad;

@@ -77,6 +77,8 @@ struct BatchInfo {
   int32_t aa_jitter;  // 1: stochastic anti-aliasing of the camera rays (extension, PtOptions.aa_jitter)
   int32_t flat;   // 1: depth 0 appends its survivors to ONE dense depth-1 list per queue (the unfused k_intersect / k_shade pair
                   // reads that); 0: to one list per (queue, iteration) (k_paths, pt_device.h RetireBuf)
+  int32_t primary_pieces;  // k_primary: a (queue, wave) strand's iterations cut into this many pieces, the first taken by the wave
+                           // itself, the others by whoever is free (an atomic counter behind ptd::Queues::deal); <= 1: one piece
   int32_t debug;  // profiling ablations (wrong results; honoured only by -DPT_ABLATE builds): 4 = skip primitive tests,
                   // 8 = skip shade_bounce
 };

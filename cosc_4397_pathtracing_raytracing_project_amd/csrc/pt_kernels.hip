@@ -1230,134 +1230,149 @@ __global__ __launch_bounds__(kBlock, kPrimaryWaves) void k_primary(SceneTables s
   const int ntop = sc.num_top;
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wib);  // (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
   const int lane = lane_id();
-  const int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
-  const Retire rt = retire_of(ret, q);
-  // The wave's samples: in iteration k the chunks jj = rho, rho + wq, ... of the queue's my_nq (chunk jj = tile chunk q + jj * Q),
-  // rho = (r + k) mod wq — its own sub-list and sub-region of (q, k) (pt_device.h RetireBuf): positions come from the two
-  // counters below, nothing is reserved with atomics and every store is issued where its group is shaded.
-  const QueueShare sh = queue_share(b, qs, q);
-  if (r == 0 && lane == 0) cnt0[(size_t)q * qs.cnt_stride] = b.K * sh.my_pixels;
-  const int64_t qbase = (int64_t)q * qs.cap;
-  const float inv_w = 1.0f / (float)cam.res_x;
-  const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
-  int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];  // flat form: the queue's ONE depth-1 list
-  const int quo = sh.my_nq / wq, rem = sh.my_nq % wq;
-  int ck = -1, crho = r == 0 ? wq - 1 : r - 1, nl = 0, nd = 0;  // iteration the counters belong to, its residue (r + ck) mod wq; survivors / retirees of the wave in it so far
-  auto publish = [&]() {  // the finished iteration's counts (also when the wave had no chunk in it: zeros)
-    if (ck >= 0 && lane == 0) rt.sub[ck * rt.wq0 + crho] = ((unsigned long long)(uint32_t)nd << 32) | (uint32_t)nl;
-  };
-  auto next_iteration = [&]() {  // publish, then on to ck + 1
-    publish();
-    nl = nd = 0;
-    ++ck;
-    crho = crho + 1 == wq ? 0 : crho + 1;
-  };
-  // shading + retirement + compaction of one group of primary rays from its resolved hit key / record
-  auto shade_group = [&](unsigned long long best, const float* rec, bool valid, int k, int pl, int slot, uint32_t phash, f3 d) {
-    const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
-    ShadeIO s;
-    s.o = o;
-    s.d = d;
-    s.c = mk(1.0f, 1.0f, 1.0f);
-    s.alive = false;
-    Bounce bo;
-    bo.kind = 0;
-    f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
-    if (valid) {
-      float ht = -1.0f;
-      int hmat = 0;
-      if (hit) {
-        ht = __uint_as_float((uint32_t)(best >> 32));
-        const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
-        hmat = G->material;
-        hn = mk(rec[0 * 64], rec[1 * 64], rec[2 * 64]);
-        hp = mk(rec[3 * 64], rec[4 * 64], rec[5 * 64]);
-        if (GRID) hn = Ar<kD0>::finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
-      }
-      bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
-    }
-    const bool alive = valid && s.alive, dead = valid && !s.alive;
-    if (alive) shade_bounce(bo, hn, hp, s);
-    const unsigned long long live = ballot(alive);
-    const PathTag tag{slot, phash, k};
-    if (b.flat) {  // unfused consumers: one dense list per queue behind an atomic, records appended one by one (test / A-B form)
-      int base = 0;
-      if (live && lane == 0) base = atomicAdd(counter, (int)__popcll(live));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (alive) path_store(out, qbase + base + rank_in(live), s.o, s.d, s.c, tag);
-      retire_append(rt, dead, k, pl, s.c);
-      return;
-    }
-    while (ck < k) next_iteration();  // first group of a new iteration: the previous one's counts are final (iterations without a chunk publish zeros on the way)
-    const int sub0 = k * rt.seg_cap + sub_offset(quo, rem, crho) * 64;  // first slot of sub-list / sub-region (q, k, rho)
-    const unsigned long long deadm = ballot(dead);
-    if (alive) path_store(out, qbase + sub0 + nl + rank_in(live), s.o, s.d, s.c, tag);
-    if (dead) rt.rec[sub0 + nd + rank_in(deadm)] = ptd::Word4{s.c.x, s.c.y, s.c.z, __int_as_float(pl)};
-    nl += (int)__popcll(live), nd += (int)__popcll(deadm);
-  };
-  // a group between its search and its shading (RING)
-  struct {
-    f3 d;
-    int k, pl, slot;
-    uint32_t phash;
-    bool valid;
-    int par, mark;
-    bool any;
-  } pp;
-  pp.any = false;
-  Carry<true, 2> rc = carry_init<true, 2>(lds + tbl + wib * kWaveBytes);  // RING only (the same bytes as `w` otherwise)
-  rc.debug = b.debug;
-  rc.qo_tab = cam_qo;
-  rc.cam_o = o;
-  int it = 0;
-  for (int k = 0, rho = r; k < b.K; ++k, rho = rho + 1 == wq ? 0 : rho + 1) {
-    for (int jj = rho; jj < sh.my_nq; jj += wq, ++it) {
-      const int pl_raw = (q + jj * qs.Q) * 64 + lane;
-      const bool valid = pl_raw < b.N;
-      const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
-      const int slot = make_slot(b, k, pl);
-      const int p = global_pixel(b, pl);  // global pixel index
-      const uint32_t phash = utilhash((uint32_t)p);
-      float jx = 0.f, jy = 0.f;
-      if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
-      const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
-      // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
-      // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
-      // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
-      const bool near_scene = ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
-                                                     sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
-      if constexpr (RING) {
-        const int par = it & 1;
-        rc.best[par * 64 + lane] = kNoHit;
-        if (near_scene) carry_search<false, 2, true, kD0>(rc, cam_top, ntop, nodes, geoms, o, d, valid, lane, par, sc.cull_margin, sc.top_xor);
-        if (pp.any) carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
-        if (pp.any) shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
-        pp.d = d, pp.k = k, pp.pl = pl, pp.slot = slot, pp.phash = phash, pp.valid = valid, pp.par = par, pp.mark = rc.appended, pp.any = true;
-      } else {
-        if (GRID) {
-          w.best[lane] = kNoHit;
-          if (near_scene) {
-            grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
-            while (cy.count > 0) carry_chunk<false, 1, kD0, true>(cy, min(64, cy.count), lane, nodes, geoms);
-          }
-        } else if (near_scene) {
-          if constexpr (!TABLES_IN_LDS && PT_PRIMARY_PACKET != 0) trace_group_packet<kD0>(w, nodes, sc.num_nodes, geoms, o, d, valid, lane, cam_qo, sc.has_triangles != 0);
-          else trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
-        } else {
-          w.best[lane] = kNoHit;
+  // A strand = what one wave of one queue traces at depth 0: in iteration k the queue's chunks of residue (r + k) mod wq.  Wave w
+  // runs strand w.  With a small tile (a rank's share of a frame: a queue owns a dozen chunks, some of them beside the scene,
+  // which cost a bounds test) the strands differ by +-20 %: they are then cut into `pieces` runs of iterations — every
+  // (queue, iteration, residue) still has ONE owner, which is all the sub-lists ask for — piece 0 stays with wave w and the
+  // others go to whoever is free, in the order of a counter (zeroed by k_count_stats).
+  const int kp = b.primary_pieces > 1 && qs.deal != nullptr && !b.flat ? (b.K + b.primary_pieces - 1) / b.primary_pieces : b.K;
+  const int pieces = (b.K + kp - 1) / kp;
+  for (int strand = wave; strand < qs.W * pieces;) {
+    const int piece = strand / qs.W, sw = strand - piece * qs.W;
+    const int k0 = piece * kp, k1 = min(b.K, k0 + kp);
+    const int q = sw % qs.Q, r = sw / qs.Q, wq = qs.W / qs.Q;
+    const Retire rt = retire_of(ret, q);
+    // The wave's samples: in iteration k the chunks jj = rho, rho + wq, ... of the queue's my_nq (chunk jj = tile chunk q + jj * Q),
+    // rho = (r + k) mod wq — its own sub-list and sub-region of (q, k) (pt_device.h RetireBuf): positions come from the two
+    // counters below, nothing is reserved with atomics and every store is issued where its group is shaded.
+    const QueueShare sh = queue_share(b, qs, q);
+    if (piece == 0 && r == 0 && lane == 0) cnt0[(size_t)q * qs.cnt_stride] = b.K * sh.my_pixels;
+    const int64_t qbase = (int64_t)q * qs.cap;
+    const float inv_w = 1.0f / (float)cam.res_x;
+    const f3 o = mk(cam.pos[0], cam.pos[1], cam.pos[2]);
+    int32_t* counter = &cnt_out[(size_t)q * qs.cnt_stride];  // flat form: the queue's ONE depth-1 list
+    const int quo = sh.my_nq / wq, rem = sh.my_nq % wq;
+    int ck = k0 - 1, crho = (r + k0 + wq - 1) % wq, nl = 0, nd = 0;  // iteration the counters belong to, its residue (r + ck) mod wq; survivors / retirees of the wave in it so far
+    auto publish = [&]() {  // the finished iteration's counts (also when the wave had no chunk in it: zeros)
+      if (ck >= k0 && lane == 0) rt.sub[ck * rt.wq0 + crho] = ((unsigned long long)(uint32_t)nd << 32) | (uint32_t)nl;
+    };
+    auto next_iteration = [&]() {  // publish, then on to ck + 1
+      publish();
+      nl = nd = 0;
+      ++ck;
+      crho = crho + 1 == wq ? 0 : crho + 1;
+    };
+    // shading + retirement + compaction of one group of primary rays from its resolved hit key / record
+    auto shade_group = [&](unsigned long long best, const float* rec, bool valid, int k, int pl, int slot, uint32_t phash, f3 d) {
+      const bool hit = (uint32_t)(best >> 32) != 0x7f7fffffu;
+      ShadeIO s;
+      s.o = o;
+      s.d = d;
+      s.c = mk(1.0f, 1.0f, 1.0f);
+      s.alive = false;
+      Bounce bo;
+      bo.kind = 0;
+      f3 hn = mk(0.f, 0.f, 0.f), hp = mk(0.f, 0.f, 0.f);
+      if (valid) {
+        float ht = -1.0f;
+        int hmat = 0;
+        if (hit) {
+          ht = __uint_as_float((uint32_t)(best >> 32));
+          const ptd::Geom* G = geoms + nodes[(uint32_t)best].geom;
+          hmat = G->material;
+          hn = mk(rec[0 * 64], rec[1 * 64], rec[2 * 64]);
+          hp = mk(rec[3 * 64], rec[4 * 64], rec[5 * 64]);
+          if (GRID) hn = Ar<kD0>::finish_normal(G, hn);  // the grid's chunks leave the normal to the winner (carry_chunk, LEAN)
         }
-        shade_group(w.best[lane], w.rec + lane, valid, k, pl, slot, phash, d);
+        bo = shade_decide(mats, b.trace_depth, 0, iter_hash_of(ihash, sc, b, 0, k) ^ phash, ht, hmat, s);
+      }
+      const bool alive = valid && s.alive, dead = valid && !s.alive;
+      if (alive) shade_bounce(bo, hn, hp, s);
+      const unsigned long long live = ballot(alive);
+      const PathTag tag{slot, phash, k};
+      if (b.flat) {  // unfused consumers: one dense list per queue behind an atomic, records appended one by one (test / A-B form)
+        int base = 0;
+        if (live && lane == 0) base = atomicAdd(counter, (int)__popcll(live));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (alive) path_store(out, qbase + base + rank_in(live), s.o, s.d, s.c, tag);
+        retire_append(rt, dead, k, pl, s.c);
+        return;
+      }
+      while (ck < k) next_iteration();  // first group of a new iteration: the previous one's counts are final (iterations without a chunk publish zeros on the way)
+      const int sub0 = k * rt.seg_cap + sub_offset(quo, rem, crho) * 64;  // first slot of sub-list / sub-region (q, k, rho)
+      const unsigned long long deadm = ballot(dead);
+      if (alive) path_store(out, qbase + sub0 + nl + rank_in(live), s.o, s.d, s.c, tag);
+      if (dead) rt.rec[sub0 + nd + rank_in(deadm)] = ptd::Word4{s.c.x, s.c.y, s.c.z, __int_as_float(pl)};
+      nl += (int)__popcll(live), nd += (int)__popcll(deadm);
+    };
+    // a group between its search and its shading (RING)
+    struct {
+      f3 d;
+      int k, pl, slot;
+      uint32_t phash;
+      bool valid;
+      int par, mark;
+      bool any;
+    } pp;
+    pp.any = false;
+    Carry<true, 2> rc = carry_init<true, 2>(lds + tbl + wib * kWaveBytes);  // RING only (the same bytes as `w` otherwise)
+    rc.debug = b.debug;
+    rc.qo_tab = cam_qo;
+    rc.cam_o = o;
+    int it = 0;
+    for (int k = k0, rho = (r + k0) % wq; k < k1; ++k, rho = rho + 1 == wq ? 0 : rho + 1) {
+      for (int jj = rho; jj < sh.my_nq; jj += wq, ++it) {
+        const int pl_raw = (q + jj * qs.Q) * 64 + lane;
+        const bool valid = pl_raw < b.N;
+        const int pl = valid ? pl_raw : b.N - 1;  // tile pixel
+        const int slot = make_slot(b, k, pl);
+        const int p = global_pixel(b, pl);  // global pixel index
+        const uint32_t phash = utilhash((uint32_t)p);
+        float jx = 0.f, jy = 0.f;
+        if (b.aa_jitter) aa_jitter(b.iter_first + k, p, jx, jy);
+        const f3 d = Ar<kD0>::camera_dir(cam, inv_w, p, b.aa_jitter != 0, jx, jy);
+        // Primary rays come in bundles of 64 neighbouring pixels and half of the 16:9 frame looks past the scene:
+        // one test against the bounds of the whole tree per lane, and if no lane passes (a parent box rejects
+        // whatever its children would, the slab arithmetic being monotone) the 7 leaf-box tests are skipped.
+        const bool near_scene = ballot(valid && Ar<kD0>::slab(o, Ar<kD0>::ray_inv(d, o), sc.root_min[0], sc.root_min[1], sc.root_min[2],
+                                                       sc.root_max[0], sc.root_max[1], sc.root_max[2])) != 0;
+        if constexpr (RING) {
+          const int par = it & 1;
+          rc.best[par * 64 + lane] = kNoHit;
+          if (near_scene) carry_search<false, 2, true, kD0>(rc, cam_top, ntop, nodes, geoms, o, d, valid, lane, par, sc.cull_margin, sc.top_xor);
+          if (pp.any) carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);  // the previous group's candidates are now all resolved
+          if (pp.any) shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
+          pp.d = d, pp.k = k, pp.pl = pl, pp.slot = slot, pp.phash = phash, pp.valid = valid, pp.par = par, pp.mark = rc.appended, pp.any = true;
+        } else {
+          if (GRID) {
+            w.best[lane] = kNoHit;
+            if (near_scene) {
+              grid_search<1, kD0>(cy, cr, sc, nodes, geoms, o, d, valid, lane, 0);
+              while (cy.count > 0) carry_chunk<false, 1, kD0, true>(cy, min(64, cy.count), lane, nodes, geoms);
+            }
+          } else if (near_scene) {
+            if constexpr (!TABLES_IN_LDS && PT_PRIMARY_PACKET != 0) trace_group_packet<kD0>(w, nodes, sc.num_nodes, geoms, o, d, valid, lane, cam_qo, sc.has_triangles != 0);
+            else trace_group<true, TABLES_IN_LDS, kD0>(w, cam_top, ntop, nodes, geoms, o, d, valid, lane, sc.cull_margin, sc.top_xor, cam_qo, sc.has_triangles != 0);
+          } else {
+            w.best[lane] = kNoHit;
+          }
+          shade_group(w.best[lane], w.rec + lane, valid, k, pl, slot, phash, d);
+        }
       }
     }
-  }
-  if constexpr (RING) {
-    if (pp.any) {
-      carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);
-      shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
+    if constexpr (RING) {
+      if (pp.any) {
+        carry_drain_to<true, 2, kD0, true>(rc, pp.mark, lane, nodes, geoms);
+        shade_group(rc.best[pp.par * 64 + lane], rc.rec + pp.par * 6 * 64 + lane, pp.valid, pp.k, pp.pl, pp.slot, pp.phash, pp.d);
+      }
     }
+    if (!b.flat)
+      while (ck < k1) next_iteration();  // the last iteration's counts, and zeros for trailing iterations without a chunk
+    if (pieces == 1) break;
+    int nx = 0;
+    if (lane == 0) nx = atomicAdd(&qs.deal[2 * qs.Q + 1], 1);
+    strand = qs.W + __builtin_amdgcn_readfirstlane(nx);
   }
-  if (!b.flat)
-    while (ck < b.K) next_iteration();  // the last iteration's counts, and zeros for trailing iterations without a chunk
 }
 
 // ── ALL depths >= 1 in one launch: persistent lanes (k_paths) ─────────────────────────────────────────────────────────────────
