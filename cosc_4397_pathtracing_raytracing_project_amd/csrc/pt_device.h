@@ -152,7 +152,8 @@ struct Queues {
   // +-25 % between queues.  deal[0 .. Q] = first wave of queue q (deal[Q] = the W the table was made for: any other launch
   // width falls back to W / Q each), deal[Q + 1 + q] = rays traced for queue q by the k_paths launch of this batch, from which
   // k_count_stats deals the next batch's waves.  Which wave traces a path changes no sample (RetireBuf).  deal[2 Q + 1]: the
-  // counter k_primary's waves take the later pieces of the strands from (BatchInfo::primary_pieces), zero between batches.
+  // counter k_primary's waves take the later pieces of the strands from (BatchInfo::primary_pieces); deal[2 Q + 2 + q]: the counter
+  // the waves of queue q take pieces of its depth-1 rays from in k_paths.  Both zero between batches (k_count_stats).
   int32_t* deal;
   int32_t paths_W;      // waves of the k_paths launches (what k_count_stats deals)
   int32_t pad;

@@ -1649,15 +1649,21 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       if (lane == (e0 >> 6) + j) csum = sum;
     }
   }
-  const int per = (total + wq - 1) / wq;
-  const int lo = min(r * per, total), hi = min(lo + per, total);
   if (r == 0 && lane == 0) cnt[per_depth * 1 + (size_t)q * qs.cnt_stride] = total;  // statistics: rays traced at depth 1
-  int ce = ne, ck = 0, crho = 0, cstart = total, ccnt = 0, clist = 0, crec = 0;  // cursor (wave-uniform): sub-list e = ck * wq0 + crho; an empty slice leaves it at the end
-  int cord = 0;          // how many sub-lists the cursor has been in before this one
-  bool append = true;    // wave-uniform, see below
+  // The queue's ranks [0, total) are cut into pieces of `ps` paths.  Piece r is the wave's own; the pieces from wq on go, in
+  // order, to whichever wave of the queue has finished what it had (a counter per queue behind ptd::Queues::deal, zeroed by
+  // k_count_stats): equal numbers of depth-1 rays are not equal work — a piece's paths come from a few dozen pixel chunks, and
+  // how long a path lives depends on where it starts (a wave of the equal-slices form was resident for 74 % of the launch on
+  // average: SQ_WAVE_CYCLES against SQ_BUSY_CYCLES).  A wave streams its pieces through ONE set of lanes: it moves on to the
+  // next piece while the last paths of the previous one are still in flight.  Which wave traces a path changes no sample.
+  const int pieces_per_wave = qs.deal != nullptr && chunk_sums && b.paths_pieces > 1 ? b.paths_pieces : 1;
+  const int ps = max((total + wq * pieces_per_wave - 1) / (wq * pieces_per_wave), 64);
+  const int npieces = (total + ps - 1) / ps;  // (more than wq of them only with the counter there)
+  int ce = ne, cstart = total, ccnt = 0, clist = 0;  // cursor (wave-uniform): sub-list e = k * wq0 + rho; nothing to stream leaves it at the end
+  int cord = 0;  // sub-list visits of the cursor so far
   // A window of 64 consecutive sub[] words in registers (lane l holds sub[win0 + l]): the cursor reads counts and retiree numbers
-  // with v_readlane instead of a dependent global load per sub-list.  With a whole 1080p frame a wave's slice touches ~25
-  // sub-lists of ~1000 paths; with an eighth of it (eight GPUs, ~190 iterations per batch) ~160 sub-lists of ~25, a fifth of
+  // with v_readlane instead of a dependent global load per sub-list.  With a whole 1080p frame a wave's piece touches a handful of
+  // sub-lists of ~1000 paths; with an eighth of it (eight GPUs, ~190 iterations per batch) dozens of sub-lists of ~25, a fifth of
   // them empty, and two memory round trips per sub-list were a fifth of the kernel's time.
   int win0 = -64;  // nothing loaded yet: no index e >= 0 lies in [-64, 0)
   unsigned long long wsub = 0ull;
@@ -1673,60 +1679,56 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
     return ((unsigned long long)hi32 << 32) | lo32;
   };
   window_to(0);
+  // The records of the paths a wave takes out of ONE visit of a sub-list fill a contiguous range of its sub-region, whatever
+  // order they arrive in, so the wave appends them in order of retirement through a counter per visit in LDS (fillc, a ring of
+  // 64: lanes of one sub-list that die together get consecutive slots, as the per-iteration counters of the earlier layouts
+  // gave).  A lane remembers the visit number of its path; the refill below keeps the ring from lapping a path in flight.
   auto cursor_bases = [&](int first_rank) {
-    const int sub0 = ck * rt.seg_cap + sub_offset(quo, rem, crho) * 64;
-    clist = sub0;
-    const int ec = min(ce, ne - 1);
+    const int ec = min(ce, ne - 1), ck = ec / wq0, crho = ec - ck * wq0;
+    clist = ck * rt.seg_cap + sub_offset(quo, rem, crho) * 64;
     window_to(ec);
-    crec = sub0 + (int)(uint32_t)(sub_word(ec) >> 32);
-    if (lane == 0) fillc[cord & 63] = crec + (first_rank - cstart);  // where this wave's first record of the sub-list goes
+    const int crec = clist + (int)(uint32_t)(sub_word(ec) >> 32);
+    if (lane == 0) fillc[cord & 63] = crec + (first_rank - cstart);  // where this wave's first record of the visit goes
   };
-  if (lo < hi) {
-    // the sub-list rank lo lies in; and how many sub-lists the slice touches.  The records of the slice's paths out of ONE
-    // sub-list fill a contiguous range of its sub-region, whatever order they arrive in, so a wave appends them in order of
-    // retirement through a counter per sub-list in LDS (fillc: lanes of one sub-list that die together get consecutive slots,
-    // as the per-iteration counters of the earlier layouts gave) — while the slice touches at most 64 of them; beyond that
-    // (tiles of a few pixels per wave) a path's record goes to the slot its own list index names.
-    int cum = 0, nsub = 0, e_begin = 0;
-    bool found = false;
-    if (chunk_sums) {  // the chunk rank lo lies in (lo < hi <= total: there is one)
+  // put the cursor on the sub-list that rank `at_rank` (< total) lies in: a new visit
+  auto seek = [&](int at_rank) {
+    int cum = 0, e_begin = 0;
+    if (chunk_sums) {
       int all;
       const int cbefore = wave_prefix6(csum, all);
-      const unsigned long long here = ballot(csum > 0 && cbefore <= lo && lo < cbefore + csum);
+      const unsigned long long here = ballot(csum > 0 && cbefore <= at_rank && at_rank < cbefore + csum);
       if (here) {
         const int l = __builtin_ctzll(here);
         e_begin = l * 64, cum = __builtin_amdgcn_readlane(cbefore, l);
       }
     }
-    for (int e0 = e_begin; e0 < ne && cum < hi; e0 += 64) {
+    for (int e0 = e_begin; e0 < ne; e0 += 64) {
       const int n = count_of(e0 + lane);
       int sum;
       const int before = wave_prefix6(n, sum);
-      if (!found) {
-        const unsigned long long here = ballot(n > 0 && cum + before <= lo && lo < cum + before + n);
-        if (here) {
-          const int l = __builtin_ctzll(here);
-          ce = e0 + l, cstart = cum + __builtin_amdgcn_readlane(before, l), ccnt = __builtin_amdgcn_readlane(n, l);
-          ck = ce / wq0, crho = ce - ck * wq0;
-          found = true;
-        }
+      const unsigned long long here = ballot(n > 0 && cum + before <= at_rank && at_rank < cum + before + n);
+      if (here) {
+        const int l = __builtin_ctzll(here);
+        ce = e0 + l, cstart = cum + __builtin_amdgcn_readlane(before, l), ccnt = __builtin_amdgcn_readlane(n, l);
+        break;
       }
-      nsub += (int)__popcll(ballot(n > 0 && cum + before < hi && cum + before + n > lo));
       cum += sum;
     }
-    append = nsub <= 64;
-    cursor_bases(lo);
-  }
-  // Path index (inside the queue's region) of the rays of global rank `rank`, for the lanes that `want` one, and what locates
-  // their retirement records: the sub-list's counter (append) or the record slot itself.  Ranks only grow, so the cursor only
-  // moves forward.  Wave-uniform control flow.
-  auto assign = [&](bool want, int rank, int& at, int& rs) {
+    ++cord;
+    cursor_bases(at_rank);
+  };
+  // Path index (inside the queue's region) of the rays of global rank `rank`, for the lanes that `want` one (consecutive ranks in
+  // lane order), and the visit their retirement records are counted under.  Ranks only grow inside a piece, so the cursor only
+  // moves forward; it stops after 31 new visits (sub-lists of a path or two: tiles of a few pixels per wave) — the lanes behind
+  // that are served by a later refill.  Returns the lanes that were served.  Wave-uniform control flow.
+  auto assign = [&](bool want, int rank, int& at, int& rs) -> unsigned long long {
     bool pending = want;
+    const int cord0 = cord;
     while (true) {
       const bool in = pending && rank < cstart + ccnt;
-      if (in) at = clist + (rank - cstart), rs = append ? (cord & 63) : crec + (rank - cstart);
+      if (in) at = clist + (rank - cstart), rs = cord;
       pending = pending && !in;
-      if (!ballot(pending) || ce >= ne) break;
+      if (!ballot(pending) || ce >= ne || cord - cord0 >= 31) break;
       cstart += ccnt;  // on to the next sub-list that holds anything: the first non-empty one behind ce in the window, else the window moves on
       ccnt = 0;
       int nxt = ce + 1;
@@ -1741,10 +1743,10 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
         nxt = win0 + 64;
       }
       ce = min(nxt, ne);
-      ck = ce / wq0, crho = ce - ck * wq0;
       ++cord;
       cursor_bases(cstart);
     }
+    return ballot(want && !pending);
   };
   const uint32_t s_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(slots));
   const uint32_t s16 = s_base + (uint32_t)lane * 16u, s4 = s_base + 2048u + (uint32_t)lane * 4u;
@@ -1753,29 +1755,39 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const float* in2 = uniform_ptr(reinterpret_cast<const float*>(in.r + 2 * in.stride) + 2 * qbase);
   PathRec nx;  // !SLOTS: the lane's next record, in registers
   nx.o = nx.d = nx.c = mk(0.f, 0.f, 0.f), nx.tag = PathTag{0, 0u, 0};
-  int nx_rs = 0;  // !SLOTS: ... and its record slot
-  int* slot_rs = reinterpret_cast<int*>(slots + 2560) + lane;  // SLOTS: the record slot of the record waiting in the lane's slot
+  int nx_rs = 0;  // !SLOTS: ... and its visit
+  int* slot_rs = reinterpret_cast<int*>(slots + 2560) + lane;  // SLOTS: the visit of the record waiting in the lane's slot
   auto fetch = [&](int at, int rs) {
     if constexpr (SLOTS) fetch_record_to_lds(in0, in1, in2, at, s_base), *slot_rs = rs;
     else nx = path_load(in, qbase + at), nx_rs = rs;
   };
   // lane state
   f3 o = mk(0.f, 0.f, 0.f), d = o, c = o;
-  int slot = 0, depth = 1, mark = 0, rslot = 0;  // rslot: the path's sub-list counter (append) / record slot, from when it was taken; at death: the record slot
+  int slot = 0, depth = 1, mark = 0, rslot = 0;  // rslot: the visit the path was taken in; from its death on: its record slot
   uint32_t phash = 0u;
   bool valid = false, fresh = false, owes = false;  // owes: the lane's path died and its retirement record is not stored yet
-  bool has_next = lo + lane < hi;
-  {
-    int at = 0, rs = 0;
-    assign(has_next, lo + lane, at, rs);
-    if (has_next) fetch(at, rs);
-  }
-  int streamed = min(lo + 64, hi);  // records handed to slots so far: [lo, streamed)
+  bool has_next = false;                            // a record is waiting in the lane's slot (on its way there)
+  int streamed = 0, p_hi = 0;  // the current piece: records [.., streamed) handed out, the piece ends at p_hi; -1: no piece left for this wave
   while (true) {
-    // ── refill: dead lanes take the record waiting in their slot; the slot gets the next record of the slice ──
+    // ── on to the wave's next piece, once the current one is handed out: its own, then whatever the queue's counter gives ──
+    if (streamed >= p_hi && p_hi >= 0) {
+      int nextp = npieces;
+      if (cord == 0) nextp = r;  // (every piece starts with a visit)
+      else if (npieces > wq) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(&qs.deal[2 * qs.Q + 2 + q], 1);
+        nextp = wq + __builtin_amdgcn_readfirstlane(v);
+      }
+      if (nextp < npieces) {
+        streamed = nextp * ps, p_hi = min(streamed + ps, total);
+        seek(streamed);
+      } else {
+        p_hi = -1;
+      }
+    }
+    // ── refill: dead lanes take the record waiting in their slot; the slot gets the next record of the piece ──
     const bool take = !valid && has_next;
-    const unsigned long long tm = ballot(take);
-    if (tm | ballot(owes)) {
+    if (ballot(take || owes || (!valid && !has_next && streamed < p_hi))) {
       v4f w0, w1;
       float cz;
       int nslot, nrs;
@@ -1801,22 +1813,32 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
 #endif
         owes = false;
       }
-      const int rank = rank_in(tm);
-      const bool more = take && streamed + rank < hi;
-      int at = 0, rs = 0;
-      assign(more, streamed + rank, at, rs);
       if (take) {
         o = mk(w0.x, w0.y, w0.z), d = mk(w0.w, w1.x, w1.y), c = mk(w1.z, w1.w, cz);
         slot = nslot, rslot = nrs;
         phash = utilhash((uint32_t)global_pixel(b, nslot & ((1 << b.slot_shift) - 1)));
         depth = 1;
         valid = fresh = true;
-        has_next = more;
-        if (more) fetch(at, rs);
+        has_next = false;
       }
-      streamed = min(streamed + (int)__popcll(tm), hi);
+      // every lane without a waiting record gets the next one of the piece — unless a path in flight was taken 32 or more visits
+      // ago: its counter in the ring of 64 must not be handed to another visit (the cursor moves by at most 31 per refill)
+      const bool lapping = ballot(valid && cord - rslot >= 32) != 0ull;
+      const bool empty = !has_next && !lapping;  // takers (just emptied) and lanes that found nothing at an earlier refill
+      const unsigned long long em = ballot(empty);
+      const int rank = rank_in(em);
+      const bool more = empty && streamed + rank < p_hi;
+      int at = 0, rs = 0;
+      const unsigned long long served = assign(more, streamed + rank, at, rs);
+      if ((served >> lane) & 1ull) {
+        has_next = true;
+        fetch(at, rs);
+      }
+      streamed += (int)__popcll(served);
     }
-    if (!ballot(valid)) break;  // every path of the slice has retired
+    // (no valid lane but records on their way, at the start of the wave: the rest of the round finds nothing to do — a `continue`
+    // here costs six VGPRs)
+    if (!ballot(valid || has_next) && p_hi < 0) break;  // every path of the wave's pieces has retired
     bool ready;
     if constexpr (MODE == 0) {
       // ── search: box tests + appends for the lanes with a new ray; full chunks as the ring fills ──
@@ -1877,7 +1899,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       }
       const bool alive = ready && s.alive, dead = ready && !s.alive;
       if (dead) atomicAdd(&died[depth & 63], 1);  // statistics: rays traced at depth d = paths retired at depth >= d
-      if (dead && append) rslot = atomicAdd(&fillc[rslot], 1);  // lanes of one sub-list get consecutive record slots
+      if (dead) rslot = atomicAdd(&fillc[rslot & 63], 1);  // lanes of one visit get consecutive record slots
       if (alive) shade_bounce(bo, hn, hp, s);
       if (ready) {
         c = s.c;
@@ -1888,12 +1910,13 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   }
   // statistics: rays traced at depth d >= 2 = this wave's paths retired at depth >= d (row 1 holds the queue's input count already)
   if (lane == 0) {
-    int reached = 0, rays = hi - lo;
+    int reached = 0, rays = 0;
     for (int dd = min(b.trace_depth - 1, 63); dd >= 2; --dd) {
       reached += died[dd];
       rays += reached;
       if (reached) atomicAdd(&cnt[per_depth * dd + (size_t)q * qs.cnt_stride], reached);
     }
+    rays += reached + died[1];  // the wave's depth-1 rays: every path it took has retired somewhere
     if (qs.deal != nullptr && rays) atomicAdd(&qs.deal[qs.Q + 1 + q], rays);  // what this queue's paths cost: the next batch's deal
   }
 }
