@@ -615,7 +615,8 @@ int run_batch(Ctx& g, int iter_first, int kb) {
     const int64_t groups = (int64_t)kb * g.qs.nq / std::max(1, g.ret.wq0);
     b.primary_pieces = e ? atoi(e) : (int)std::min<int64_t>(4, std::max<int64_t>(1, groups / 48));
     const char* ep = getenv("PT_PATHS_PIECES");  // experiment knob
-    b.paths_pieces = ep ? atoi(ep) : 4;
+    const char* em = getenv("PT_PATHS_MIN_PIECE");  // test knob: pieces of a few paths, so that small images exercise the piece switches
+    b.paths_pieces = (ep ? std::min(std::max(atoi(ep), 1), 0x7fff) : 8) | (em ? std::min(std::max(atoi(em), 1), 0x7fff) : 64) << 16;
   }
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;

@@ -79,8 +79,8 @@ struct BatchInfo {
                   // reads that); 0: to one list per (queue, iteration) (k_paths, pt_device.h RetireBuf)
   int32_t primary_pieces;  // k_primary: a (queue, wave) strand's iterations cut into this many pieces, the first taken by the wave
                            // itself, the others by whoever is free (an atomic counter behind ptd::Queues::deal); <= 1: one piece
-  int32_t paths_pieces;    // k_paths: a queue's depth-1 rays cut into this many pieces per wave, one its own, the others first come, first
-                           // served (counters behind ptd::Queues::deal); <= 1: one piece per wave
+  int32_t paths_pieces;    // k_paths: low 16 bits: a queue's depth-1 rays cut into this many pieces per wave, one its own, the others first
+                           // come, first served (counters behind ptd::Queues::deal); <= 1: one piece per wave; high 16 bits: fewest paths in a piece
   int32_t debug;  // profiling ablations (wrong results; honoured only by -DPT_ABLATE builds): 4 = skip primitive tests,
                   // 8 = skip shade_bounce
 };

@@ -1626,9 +1626,10 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const size_t per_depth = (size_t)qs.Q * qs.cnt_stride;
   const int64_t qbase = (int64_t)q * qs.cap;
   // The queue's depth-1 rays: k_primary's sub-lists (k, rho), e = k * wq0 + rho, concatenated in that order (their survivor
-  // counts — the low words of sub[e] — are final before this launch).  The wave takes the slice [lo, hi) of global ranks and
-  // walks it front to back with a cursor: the sub-list the next rank lies in, where that sub-list starts in the queue's path
-  // region, and where the records of its paths go — slot retirees(e) + i of sub-region e for the path at index i (RetireBuf).
+  // counts — the low words of sub[e] — are final before this launch).  A wave takes pieces [p * ps, (p + 1) * ps) of the global
+  // ranks and walks each front to back with a cursor: the sub-list the next rank lies in, where that sub-list starts in the queue's
+  // path region, and where the records of its paths go — the slots from retirees(e) + i on in sub-region e for the paths from
+  // index i on (RetireBuf).
   const int wq0 = rt.wq0, ne = b.K * wq0;
   const int my_nq = queue_share(b, qs, q).my_nq, quo = my_nq / wq0, rem = my_nq % wq0;
   auto count_of = [&](int e) { return e < ne ? (int)(uint32_t)rt.sub[e] : 0; };
@@ -1656,8 +1657,8 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   // how long a path lives depends on where it starts (a wave of the equal-slices form was resident for 74 % of the launch on
   // average: SQ_WAVE_CYCLES against SQ_BUSY_CYCLES).  A wave streams its pieces through ONE set of lanes: it moves on to the
   // next piece while the last paths of the previous one are still in flight.  Which wave traces a path changes no sample.
-  const int pieces_per_wave = qs.deal != nullptr && chunk_sums && b.paths_pieces > 1 ? b.paths_pieces : 1;
-  const int ps = max((total + wq * pieces_per_wave - 1) / (wq * pieces_per_wave), 64);
+  const int pieces_per_wave = qs.deal != nullptr && chunk_sums && (b.paths_pieces & 0xffff) > 1 ? (b.paths_pieces & 0xffff) : 1;
+  const int ps = max((total + wq * pieces_per_wave - 1) / (wq * pieces_per_wave), b.paths_pieces >> 16);  // (not less than a refill's worth; tests: less)
   const int npieces = (total + ps - 1) / ps;  // (more than wq of them only with the counter there)
   int ce = ne, cstart = total, ccnt = 0, clist = 0;  // cursor (wave-uniform): sub-list e = k * wq0 + rho; nothing to stream leaves it at the end
   int cord = 0;  // sub-list visits of the cursor so far
@@ -1684,7 +1685,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   // 64: lanes of one sub-list that die together get consecutive slots, as the per-iteration counters of the earlier layouts
   // gave).  A lane remembers the visit number of its path; the refill below keeps the ring from lapping a path in flight.
   auto cursor_bases = [&](int first_rank) {
-    const int ec = min(ce, ne - 1), ck = ec / wq0, crho = ec - ck * wq0;
+    const int ec = min(ce, ne - 1), ck = ec / wq0, crho = ec - ck * wq0;  // (wave-uniform: scalar instructions)
     clist = ck * rt.seg_cap + sub_offset(quo, rem, crho) * 64;
     window_to(ec);
     const int crec = clist + (int)(uint32_t)(sub_word(ec) >> 32);
@@ -1823,7 +1824,11 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       }
       // every lane without a waiting record gets the next one of the piece — unless a path in flight was taken 32 or more visits
       // ago: its counter in the ring of 64 must not be handed to another visit (the cursor moves by at most 31 per refill)
+#ifdef PT_EXP_NO_LAP_GUARD  // timing experiment only (records of tiny sub-lists may collide)
+      const bool lapping = false;
+#else
       const bool lapping = ballot(valid && cord - rslot >= 32) != 0ull;
+#endif
       const bool empty = !has_next && !lapping;  // takers (just emptied) and lanes that found nothing at an earlier refill
       const unsigned long long em = ballot(empty);
       const int rank = rank_in(em);

@@ -34,6 +34,13 @@ for seed in range(first, first + count):
     path = scenes.write_scene(text, os.path.join(d, f"s{seed}.txt"))
     sc = capi.Scene(path, res=res)
     kw = dict(kw, debug_flags=flags)
+    # every other seed: k_paths' pieces of three paths and k_primary's strands in three pieces, so that small images go through the
+    # piece switches, the guarded counter ring and the strand counter (same image)
+    for name in ("PT_PATHS_MIN_PIECE", "PT_PRIMARY_PIECES"):
+        if seed % 2:
+            os.environ[name] = "3"
+        else:
+            os.environ.pop(name, None)
     r = capi.Renderer(sc, **kw); r.render(1, spp); img = r.readback(); r_tight = r.stats().tight_leaves; r.free()
     ob.load_scene(path, res=res)
     ref = ob.render(1, spp, depth=depth, variant=ob.RETIRE, nthreads=min(16, os.cpu_count() or 1))
