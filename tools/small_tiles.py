@@ -27,6 +27,6 @@ for world in worlds:
                 best=min(best,dt)
             line+=f"  {steps} steps {best*1e3:8.3f} ms = {n*steps/best/1e6:6.0f} M/s"
         st=r.stats()
-        line+=f"   k_paths {st.intersect_ms/max(1,st.intersect_launches)*1e3:7.1f} us/launch"
+        line+=f"   k_paths {st.intersect_ms/max(1,st.intersect_launches)*1e3:7.1f} us/launch, {st.grid_blocks} blocks, waves per queue {st.paths_waves>>16}-{st.paths_waves&0xffff}"
         print(line, flush=True)
         r.free()
