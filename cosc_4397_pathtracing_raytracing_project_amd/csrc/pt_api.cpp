@@ -616,7 +616,7 @@ int run_batch(Ctx& g, int iter_first, int kb) {
     b.primary_pieces = e ? atoi(e) : (int)std::min<int64_t>(4, std::max<int64_t>(1, groups / 48));
     const char* ep = getenv("PT_PATHS_PIECES");  // experiment knob
     const char* em = getenv("PT_PATHS_MIN_PIECE");  // test knob: pieces of a few paths, so that small images exercise the piece switches
-    b.paths_pieces = (ep ? std::min(std::max(atoi(ep), 1), 0x7fff) : 8) | (em ? std::min(std::max(atoi(em), 1), 0x7fff) : 64) << 16;
+    b.paths_pieces = (ep ? std::min(std::max(atoi(ep), 1), 0x7fff) : 2) | (em ? std::min(std::max(atoi(em), 1), 0x7fff) : 64) << 16;
   }
   b.stripe = g.stripe;
   b.gap = g.stripe ? g.stripe_stride - g.stripe : 0;

@@ -1657,9 +1657,12 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   // how long a path lives depends on where it starts (a wave of the equal-slices form was resident for 74 % of the launch on
   // average: SQ_WAVE_CYCLES against SQ_BUSY_CYCLES).  A wave streams its pieces through ONE set of lanes: it moves on to the
   // next piece while the last paths of the previous one are still in flight.  Which wave traces a path changes no sample.
+  // Piece sizes fall: the pieces of level l = p / wq hold ps0 (1 - 1 / P)^l paths (not fewer than a refill's worth; tests: fewer),
+  // ps0 = total / (wq P), P = paths_pieces, so that the levels add up to the queue — large pieces while everybody is busy, small
+  // ones at the end, where a launch waits for the last piece (pieces of one size left half a piece of idle time per wave).
   const int pieces_per_wave = qs.deal != nullptr && chunk_sums && (b.paths_pieces & 0xffff) > 1 ? (b.paths_pieces & 0xffff) : 1;
-  const int ps = max((total + wq * pieces_per_wave - 1) / (wq * pieces_per_wave), b.paths_pieces >> 16);  // (not less than a refill's worth; tests: less)
-  const int npieces = (total + ps - 1) / ps;  // (more than wq of them only with the counter there)
+  const int ps_min = b.paths_pieces >> 16;
+  const int ps0 = max((total + wq * pieces_per_wave - 1) / (wq * pieces_per_wave), ps_min);
   int ce = ne, cstart = total, ccnt = 0, clist = 0;  // cursor (wave-uniform): sub-list e = k * wq0 + rho; nothing to stream leaves it at the end
   int cord = 0;  // sub-list visits of the cursor so far
   // A window of 64 consecutive sub[] words in registers (lane l holds sub[win0 + l]): the cursor reads counts and retiree numbers
@@ -1721,8 +1724,8 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   // Path index (inside the queue's region) of the rays of global rank `rank`, for the lanes that `want` one (consecutive ranks in
   // lane order), and the visit their retirement records are counted under.  Ranks only grow inside a piece, so the cursor only
   // moves forward; it stops after 31 new visits (sub-lists of a path or two: tiles of a few pixels per wave) — the lanes behind
-  // that are served by a later refill.  Returns the lanes that were served.  Wave-uniform control flow.
-  auto assign = [&](bool want, int rank, int& at, int& rs) -> unsigned long long {
+  // that are served by a later refill.  Returns whether the lane was served.  Wave-uniform control flow.
+  auto assign = [&](bool want, int rank, int& at, int& rs) -> bool {
     bool pending = want;
     const int cord0 = cord;
     while (true) {
@@ -1747,7 +1750,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       ++cord;
       cursor_bases(cstart);
     }
-    return ballot(want && !pending);
+    return want && !pending;
   };
   const uint32_t s_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_offset(slots));
   const uint32_t s16 = s_base + (uint32_t)lane * 16u, s4 = s_base + 2048u + (uint32_t)lane * 4u;
@@ -1772,15 +1775,23 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   while (true) {
     // ── on to the wave's next piece, once the current one is handed out: its own, then whatever the queue's counter gives ──
     if (streamed >= p_hi && p_hi >= 0) {
-      int nextp = npieces;
+      int nextp = -1;
       if (cord == 0) nextp = r;  // (every piece starts with a visit)
-      else if (npieces > wq) {
+      else if (ps0 * wq < total) {  // (level 0 does not cover the queue: there is a counter)
         int v = 0;
         if (lane == 0) v = atomicAdd(&qs.deal[2 * qs.Q + 2 + q], 1);
         nextp = wq + __builtin_amdgcn_readfirstlane(v);
       }
-      if (nextp < npieces) {
-        streamed = nextp * ps, p_hi = min(streamed + ps, total);
+      int start = total, sz = ps0;
+      if (nextp >= 0) {
+        start = 0;
+        int level = nextp / wq;
+        const int idx = nextp - level * wq;
+        for (; level > 0 && start < total; --level) start += wq * sz, sz = max(sz - sz / pieces_per_wave, ps_min);
+        start += idx * sz;
+      }
+      if (start < total) {
+        streamed = start, p_hi = min(start + sz, total);
         seek(streamed);
       } else {
         p_hi = -1;
@@ -1834,12 +1845,12 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       const int rank = rank_in(em);
       const bool more = empty && streamed + rank < p_hi;
       int at = 0, rs = 0;
-      const unsigned long long served = assign(more, streamed + rank, at, rs);
-      if ((served >> lane) & 1ull) {
+      const bool served = assign(more, streamed + rank, at, rs);
+      if (served) {
         has_next = true;
         fetch(at, rs);
       }
-      streamed += (int)__popcll(served);
+      streamed += (int)__popcll(ballot(served));
     }
     // (no valid lane but records on their way, at the start of the wave: the rest of the round finds nothing to do — a `continue`
     // here costs six VGPRs)
