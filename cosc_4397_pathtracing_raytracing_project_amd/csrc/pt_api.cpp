@@ -1039,8 +1039,8 @@ int setup(Ctx& g, const PtSceneDesc* sc, const PtOptions& opt) {
   HIP_OK(hipMemset(g.d_cnt, 0, (size_t)(g.depth + 1) * Q * g.qs.cnt_stride * sizeof(int32_t)));  // k_count_stats re-zeroes it after every batch
   if (dalloc(g, &g.d_stats, PT_MAX_DEPTH)) return -1;
   if (!getenv("PT_NO_DEAL")) {  // (A/B knob: W / Q waves per queue in every batch; same image)
-    if (dalloc(g, &g.qs.deal, 3 * (size_t)Q + 2)) return -1;
-    HIP_OK(hipMemset(g.qs.deal, 0, (3 * (size_t)Q + 2) * sizeof(int32_t)));  // nothing measured yet: W / Q each
+    if (dalloc(g, &g.qs.deal, 4 * (size_t)Q + 2)) return -1;
+    HIP_OK(hipMemset(g.qs.deal, 0, (4 * (size_t)Q + 2) * sizeof(int32_t)));  // nothing measured yet: W / Q each
   }
   HIP_OK(hipMemset(g.d_image, 0, 3 * (size_t)g.N * sizeof(float)));
   HIP_OK(hipMemset(g.d_stats, 0, PT_MAX_DEPTH * sizeof(unsigned long long)));

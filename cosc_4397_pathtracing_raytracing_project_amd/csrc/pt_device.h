@@ -150,8 +150,8 @@ struct Queues {
   // k_paths' waves dealt to the queues by MEASURED work (null: W / Q each).  A queue owns the same pixels in every iteration, so
   // the rays its paths cost repeat from batch to batch, and with a small tile (a rank's share of a frame) they differ by
   // +-25 % between queues.  deal[0 .. Q] = first wave of queue q (deal[Q] = the W the table was made for: any other launch
-  // width falls back to W / Q each), deal[Q + 1 + q] = rays traced for queue q by the k_paths launch of this batch, from which
-  // k_count_stats deals the next batch's waves.  Which wave traces a path changes no sample (RetireBuf).  deal[2 Q + 1]: the
+  // width falls back to W / Q each), deal[Q + 1 + q] = time the waves of queue q spent in the k_paths launch of this batch (0.64-us
+  // units) and deal[3 Q + 2 + q] = the rays they traced, from which k_count_stats deals the next batch's waves.  Which wave traces a path changes no sample (RetireBuf).  deal[2 Q + 1]: the
   // counter k_primary's waves take the later pieces of the strands from (BatchInfo::primary_pieces); deal[2 Q + 2 + q]: the counter
   // the waves of queue q take pieces of its depth-1 rays from in k_paths.  Both zero between batches (k_count_stats).
   int32_t* deal;

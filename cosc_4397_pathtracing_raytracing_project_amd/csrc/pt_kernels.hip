@@ -1612,6 +1612,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wib);  // (the compiler cannot see that threadIdx.x >> 6 is wave-uniform)
   const int lane = lane_id();
   died[lane] = 0;
+  const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();  // (100 MHz, whatever the shader clock does)
   // Which queue the wave serves, as which of how many: W / Q waves per queue, or — once a batch has been measured — the
   // queue's share of the W waves by the rays its paths cost in the previous batch (ptd::Queues::deal).
   int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
@@ -1932,8 +1933,13 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
       rays += reached;
       if (reached) atomicAdd(&cnt[per_depth * dd + (size_t)q * qs.cnt_stride], reached);
     }
-    rays += reached + died[1];  // the wave's depth-1 rays: every path it took has retired somewhere
-    if (qs.deal != nullptr && rays) atomicAdd(&qs.deal[qs.Q + 1 + q], rays);  // what this queue's paths cost: the next batch's deal
+    // What this queue's paths cost, for the next batch's deal: the TIME its waves spent on them (the waves of a queue finish together
+    // — they share its pieces — so the sum is waves x the queue's finishing time, and dealing in proportion to it moves the
+    // finishing times together whatever a ray costs where).  Rays traced were the first measure: an eighth of 1080p kept waves
+    // resident for 73 % of the launch with it.
+    rays += reached + died[1];  // (the wave's rays: every path it took has retired somewhere)
+    const int ticks = (int)min((uint64_t)(__builtin_amdgcn_s_memrealtime() - t_begin) >> 6, (uint64_t)0x3ffff);  // units of 0.64 us; a queue's sum stays below 2^31
+    if (qs.deal != nullptr && rays) atomicAdd(&qs.deal[qs.Q + 1 + q], ticks), atomicAdd(&qs.deal[3 * qs.Q + 2 + q], rays);
   }
 }
 
