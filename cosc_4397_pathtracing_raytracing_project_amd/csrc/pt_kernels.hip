@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? kPathsWaves : MODE == 1 ? PT_PA
   died[lane] = 0;
   const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();  // (100 MHz, whatever the shader clock does)
   // Which queue the wave serves, as which of how many: W / Q waves per queue, or — once a batch has been measured — the
-  // queue's share of the W waves by the rays its paths cost in the previous batch (ptd::Queues::deal).
+  // queue's share of the W waves by the time its waves took in the previous batch (ptd::Queues::deal).
   int q = wave % qs.Q, r = wave / qs.Q, wq = qs.W / qs.Q;
   if (qs.deal != nullptr && qs.deal[qs.Q] == qs.W) {
     int at_or_before = 0;  // first[] is strictly increasing: the queues whose first wave is <= this wave

@@ -157,8 +157,8 @@ typedef struct PtStats {
   int32_t tight_leaves;               /* sphere leaves whose traversal box was tightened from the reference's box of the
                                          transformed unit cube to the box of the ellipsoid (large scenes; same image)     */
   int32_t paths_waves;                /* 0: every queue has the same number of waves in the fused bounce kernel; otherwise
-                                         fewest << 16 | most waves a queue gets in the next batch — dealt by the rays the
-                                         queues' paths cost in the last one (small tiles; same image, PT_NO_DEAL=1 turns it off) */
+                                         fewest << 16 | most waves a queue gets in the next batch — dealt by the time the
+                                         queues' waves took in the last one (small tiles; same image, PT_NO_DEAL=1 turns it off) */
 } PtStats;
 
 /* ---- scene loading (host).  Replaces `new Scene(file)` (src/main.cpp:45,

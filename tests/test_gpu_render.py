@@ -164,7 +164,7 @@ def test_striped_tiles_compose(scene_dir):
 
 
 def test_waves_dealt_by_measured_work_change_no_sample(scene_dir, oracle, monkeypatch):
-    """k_paths' waves are dealt to the queues by the rays the queues' paths cost in the previous batch (ptd::Queues::deal): on a
+    """k_paths' waves are dealt to the queues by the time the queues' waves took in the previous batch (ptd::Queues::deal): on a
     rank's tile of an eight-way split the queues differ enough for the deal to take effect (PtStats.paths_waves), and the image
     over several batches — the first with W / Q waves each, the rest dealt — is the oracle's bit for bit, and equal to the image
     with the deal switched off.  A whole small frame with few queues: queues too close together, no deal."""
